@@ -1,0 +1,211 @@
+"""ctypes binding of the CPU oracle (oracle/lpbox_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product path (accelerated-lpbox-admm_amd/) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "liblpbox_oracle.so")
+
+ORDER_EIGEN = 0
+ORDER_GPU = 1
+
+_dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+
+def build(force=False):
+    srcs = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith((".c", ".h"))]
+    if force or not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in srcs):
+        subprocess.check_call(["make", "-s", "-C", HERE])
+    return LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB):
+        build()
+    L = C.CDLL(LIB)
+    L.lpo_create.restype = C.c_void_p
+    L.lpo_create.argtypes = [C.c_int]
+    L.lpo_destroy.argtypes = [C.c_void_p]
+    L.lpo_set_order.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.lpo_set_verbose.argtypes = [C.c_void_p, C.c_int]
+    L.lpo_set_problem.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _ip, _ip, C.c_void_p, _dp, _dp]
+    L.lpo_read_files.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int]
+    L.lpo_init.argtypes = [C.c_void_p]
+    L.lpo_iters.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.lpo_iters_l2f.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, C.c_int]
+    for f in ("lpo_get_n", "lpo_get_org_n", "lpo_get_l", "lpo_get_iter", "lpo_get_x_iters_rows",
+              "lpo_check_infeasible_lpbox", "lpo_check_infeasible_l2f", "lpo_last_plain_iter_plus1",
+              "lpo_last_pcg_iters", "lpo_last_stop_reason"):
+        getattr(L, f).argtypes = [C.c_void_p]
+        getattr(L, f).restype = C.c_int
+    for f in ("lpo_total_pcg_iters", "lpo_total_outer_iters"):
+        getattr(L, f).argtypes = [C.c_void_p]
+        getattr(L, f).restype = C.c_long
+    L.lpo_get_x_iters.argtypes = [C.c_void_p, C.c_int, _dp]
+    L.lpo_get_x_sol.argtypes = [C.c_void_p, _dp]
+    L.lpo_get_final_x_sol.argtypes = [C.c_void_p, _dp]
+    L.lpo_cal_obj.argtypes = [C.c_void_p]
+    L.lpo_cal_obj.restype = C.c_double
+    L.lpo_cur_bin_obj.argtypes = [C.c_void_p]
+    L.lpo_cur_bin_obj.restype = C.c_double
+    L.lpo_get_vec.argtypes = [C.c_void_p, C.c_char_p, _dp, C.c_int]
+    L.lpo_get_scalar.argtypes = [C.c_void_p, C.c_char_p]
+    L.lpo_get_scalar.restype = C.c_double
+    L.lpo_get_pcg_trace.argtypes = [C.c_void_p, _ip, C.c_int]
+    _lib = L
+    return L
+
+
+class LpOracle:
+    """Mirror of the reference's PyLPboxADMMsolver (lpbox.pyx:7-76) on the CPU oracle."""
+
+    def __init__(self, print_info=0, order=ORDER_EIGEN, T=512, verbose=False):
+        self.L = lib()
+        self.h = C.c_void_p(self.L.lpo_create(int(print_info)))
+        self.L.lpo_set_order(self.h, order, T)
+        self.L.lpo_set_verbose(self.h, int(verbose))
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.lpo_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # -- problem input --
+    def set_problem(self, n, l, colptr, rowidx, b, f=None, vals=None):
+        colptr = np.ascontiguousarray(colptr, np.int32)
+        rowidx = np.ascontiguousarray(rowidx, np.int32)
+        b = np.ascontiguousarray(b, np.float64)
+        f = np.ones(l) if f is None else np.ascontiguousarray(f, np.float64)
+        vp = None
+        if vals is not None:
+            vals = np.ascontiguousarray(vals, np.float64)
+            vp = vals.ctypes.data_as(C.c_void_p)
+        rc = self.L.lpo_set_problem(self.h, n, l, len(rowidx), colptr, rowidx, vp, b, f)
+        if rc != 0:
+            raise ValueError(f"lpo_set_problem failed: {rc}")
+
+    def read_files(self, path_C, path_b, k=100):
+        rc = self.L.lpo_read_files(self.h, path_C.encode(), path_b.encode(), k)
+        if rc != 0:
+            raise IOError(f"lpo_read_files failed: {rc}")
+
+    # -- the pyx surface --
+    def solve_init(self):
+        rc = self.L.lpo_init(self.h)
+        if rc < 0:
+            raise RuntimeError(f"lpo_init failed: {rc}")
+        return rc
+
+    def solve_iter(self, i, j):
+        rc = self.L.lpo_iters(self.h, int(i), int(j))
+        if rc < 0:
+            raise RuntimeError(f"lpo_iters failed: {rc}")
+        return rc
+
+    def solve_iter_l2f(self, i, j, vec, num):
+        vec = np.ascontiguousarray(vec, np.float64)
+        rc = self.L.lpo_iters_l2f(self.h, int(i), int(j), vec, int(num))
+        if rc < 0:
+            raise RuntimeError(f"lpo_iters_l2f failed: {rc}")
+        return rc
+
+    def get_n(self):
+        return self.L.lpo_get_n(self.h)
+
+    def get_org_n(self):
+        return self.L.lpo_get_org_n(self.h)
+
+    def get_iter(self):
+        return self.L.lpo_get_iter(self.h)
+
+    def get_x_iters_2d(self, ws):
+        rows = self.L.lpo_get_x_iters_rows(self.h)
+        out = np.zeros((rows, ws))
+        if rows:
+            self.L.lpo_get_x_iters(self.h, ws, out)
+        return out
+
+    def get_x_sol(self, n=None):
+        out = np.zeros(self.get_org_n())
+        self.L.lpo_get_x_sol(self.h, out)
+        return out.reshape(-1, 1)
+
+    def get_final_x_sol(self, n=None):
+        out = np.zeros(self.get_org_n())
+        k = self.L.lpo_get_final_x_sol(self.h, out)
+        return out[:k].reshape(-1, 1)
+
+    def cal_Obj(self):
+        return self.L.lpo_cal_obj(self.h)
+
+    def get_curBinObj(self):
+        return self.L.lpo_cur_bin_obj(self.h)
+
+    def check_infeasible_lpbox(self):
+        return self.L.lpo_check_infeasible_lpbox(self.h)
+
+    def check_infeasible_l2f(self):
+        return self.L.lpo_check_infeasible_l2f(self.h)
+
+    # -- inspection --
+    def vec(self, name):
+        cap = max(self.get_org_n(), self.L.lpo_get_l(self.h)) + 8
+        out = np.zeros(cap)
+        k = self.L.lpo_get_vec(self.h, name.encode(), out, cap)
+        if k < 0:
+            raise KeyError(name)
+        return out[:k].copy()
+
+    def scalar(self, name):
+        return self.L.lpo_get_scalar(self.h, name.encode())
+
+    def pcg_trace(self):
+        out = np.zeros(32768, np.int32)
+        k = self.L.lpo_get_pcg_trace(self.h, out, len(out))
+        return out[:k].copy()
+
+    @property
+    def total_pcg_iters(self):
+        return self.L.lpo_total_pcg_iters(self.h)
+
+    @property
+    def total_outer_iters(self):
+        return self.L.lpo_total_outer_iters(self.h)
+
+    @property
+    def last_stop_reason(self):
+        return self.L.lpo_last_stop_reason(self.h)
+
+    @property
+    def last_plain_iter_plus1(self):
+        return self.L.lpo_last_plain_iter_plus1(self.h)
+
+
+def load_lp_batch(path):
+    """Split a tests/golden/lp_*.npz fixture into per-instance dicts (n, l, colptr, rowidx, b=-price)."""
+    d = np.load(path)
+    out = []
+    cp = ri = pr = 0
+    for n, l, nnz in zip(d["n"], d["l"], d["nnz"]):
+        n, l, nnz = int(n), int(l), int(nnz)
+        out.append(dict(n=n, l=l, colptr=d["colptr"][cp:cp + n + 1].astype(np.int32),
+                        rowidx=d["rowidx"][ri:ri + nnz].astype(np.int32),
+                        b=-1.0 * d["price"][pr:pr + n]))
+        cp += n + 1; ri += nnz; pr += n
+    return out
