@@ -1,0 +1,83 @@
+"""ctypes loader for liblpbox_hip.so (the C-ABI declared in include/lpbox_hip.h).
+
+There is no CPU fallback: if the library is missing this module raises, and every compute call fails
+with LPBOX_E_NODEVICE when no HIP device is present.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "liblpbox_hip.so")
+
+FLAVOUR_LP = 0
+FLAVOUR_SEG = 1
+
+_dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+# every symbol include/lpbox_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "lpbox_version": (C.c_char_p, []),
+    "lpbox_last_error": (C.c_char_p, []),
+    "lpbox_device_count": (C.c_int, []),
+    "lpbox_set_device": (C.c_int, [C.c_int]),
+    "lpbox_create": (C.c_void_p, [C.c_int, C.c_int, C.c_int]),
+    "lpbox_destroy": (None, [C.c_void_p]),
+    "lpbox_set_problem_lp": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _ip, _ip, C.c_void_p, _dp, C.c_void_p]),
+    "lpbox_read_files_lp": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_int]),
+    "lpbox_read_file": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int]),
+    "lpbox_init": (C.c_int, [C.c_void_p]),
+    "lpbox_iterate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "lpbox_iterate_l2f": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p]),
+    "lpbox_get_n": (C.c_int, [C.c_void_p, C.c_int]),
+    "lpbox_get_org_n": (C.c_int, [C.c_void_p, C.c_int]),
+    "lpbox_get_l": (C.c_int, [C.c_void_p, C.c_int]),
+    "lpbox_get_iter": (C.c_int, [C.c_void_p, C.c_int]),
+    "lpbox_get_x_iters": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "lpbox_get_x_sol": (C.c_int, [C.c_void_p, C.c_int, _dp]),
+    "lpbox_get_final_x_sol": (C.c_int, [C.c_void_p, C.c_int, _dp]),
+    "lpbox_cal_obj": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
+    "lpbox_cur_bin_obj": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
+    "lpbox_check_infeasible_lpbox": (C.c_int, [C.c_void_p, C.c_int]),
+    "lpbox_check_infeasible_l2f": (C.c_int, [C.c_void_p, C.c_int]),
+    "lpbox_get_config": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "lpbox_get_counters": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    "lpbox_get_stop": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "lpbox_kernel_time": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]),
+    "lpbox_debug_get_vec": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, _dp, C.c_int]),
+    "lpbox_debug_get_scalar": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.POINTER(C.c_double)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library once; raise ImportError (loudly) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make -C accelerated-lpbox-admm_amd/csrc` "
+            "(or __graft_entry__.build()). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class LpboxError(RuntimeError):
+    pass
+
+
+def check(rc, what="lpbox call"):
+    """Turn a negative status into a Python exception carrying lpbox_last_error()."""
+    if rc is not None and rc < 0:
+        msg = load().lpbox_last_error()
+        raise LpboxError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+    return rc

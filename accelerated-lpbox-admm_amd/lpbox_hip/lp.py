@@ -1,0 +1,314 @@
+"""Host-side mirror of the reference's LP solver interface on top of the C-ABI (include/lpbox_hip.h).
+
+`PyLPboxADMMsolver` has exactly the methods of the reference's Cython class
+(LinerProgramming/LinearProgramming/cython_solver/lpbox.pyx:7-76, "LP pyx" below); `LpBatch` is the batched
+extension: B independent instances, one workgroup (one CU) each, per launch.
+
+Reference citations: LPcpp = LinerProgramming/LinearProgramming/cython_solver/LPboxADMMsolver.cpp.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import LpboxError, check  # noqa: F401
+
+STOP_NAMES = {0: None, 1: "y1_y2", 2: "obj_std", 3: "pcg_alpha_negative", 4: "all_fixed"}
+
+
+def _as_int(v, name):
+    """Cython's `int` argument conversion accepts integral floats such as 1e4 (LP/cython_solver/test.py:10)."""
+    iv = int(v)
+    if iv != v:
+        raise TypeError(f"{name} must be integral, got {v!r}")
+    return iv
+
+
+class LpBatch:
+    """B independent LP instances solved together on one GPU (extension; no reference counterpart).
+
+    instances: iterable of dicts with keys n, l, colptr, rowidx (CSC of E, 0/1 pattern), b (already negated,
+    LPcpp:2520) and optionally f (default ones, LPcpp:2522).
+    """
+
+    def __init__(self, instances=None, print_info=0, device=None, batch=None):
+        self._L = _lib.load()
+        if device is not None:
+            check(self._L.lpbox_set_device(int(device)), "lpbox_set_device")
+        instances = list(instances) if instances is not None else None
+        self.B = len(instances) if instances is not None else int(batch)
+        self.print_info = int(print_info)
+        h = self._L.lpbox_create(_lib.FLAVOUR_LP, self.B, self.print_info)
+        if not h:
+            check(-2, "lpbox_create")
+        self._h = C.c_void_p(h)
+        if instances is not None:
+            for i, I in enumerate(instances):
+                self.set_problem(i, I["n"], I["l"], I["colptr"], I["rowidx"], I["b"], I.get("f"))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.lpbox_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- problem input ----
+    def set_problem(self, idx, n, l, colptr, rowidx, b, f=None, vals=None):
+        colptr = np.ascontiguousarray(colptr, np.int32)
+        rowidx = np.ascontiguousarray(rowidx, np.int32)
+        b = np.ascontiguousarray(b, np.float64)
+        fp = vp = None
+        if f is not None:
+            f = np.ascontiguousarray(f, np.float64)
+            fp = f.ctypes.data_as(C.c_void_p)
+        if vals is not None:
+            vals = np.ascontiguousarray(vals, np.float64)
+            vp = vals.ctypes.data_as(C.c_void_p)
+        check(self._L.lpbox_set_problem_lp(self._h, idx, int(n), int(l), len(rowidx), colptr, rowidx, vp, b, fp),
+              "lpbox_set_problem_lp")
+
+    def read_files(self, idx, path_C, path_b, k=100):
+        check(self._L.lpbox_read_files_lp(self._h, idx, os.fsencode(path_C), os.fsencode(path_b), int(k)),
+              "lpbox_read_files_lp")
+
+    def read_file(self, idx, i, k, j, root=None):
+        r = os.fsencode(root) if root is not None else None
+        check(self._L.lpbox_read_file(self._h, idx, r, int(i), int(k), int(j)), "lpbox_read_file")
+
+    # ---- solver ----
+    def solve_init(self):
+        return check(self._L.lpbox_init(self._h), "lpbox_init")
+
+    def solve_iter(self, i, j):
+        rets = np.zeros(self.B, np.int32)
+        check(self._L.lpbox_iterate(self._h, _as_int(i, "i"), _as_int(j, "j"), rets.ctypes.data_as(C.c_void_p)),
+              "lpbox_iterate")
+        return rets
+
+    def solve_iter_l2f(self, i, j, vecs=None, nums=None):
+        rets = np.zeros(self.B, np.int32)
+        vp = npn = None
+        stride = 0
+        if nums is not None and np.any(np.asarray(nums) != 0):
+            vecs = np.ascontiguousarray(vecs, np.float64).reshape(self.B, -1)
+            stride = vecs.shape[1]
+            nums = np.ascontiguousarray(nums, np.int32)
+            for b in range(self.B):
+                if nums[b] and stride < self.get_n(b):
+                    raise ValueError("fix vector shorter than the number of live variables")
+            vp = vecs.ctypes.data_as(C.c_void_p)
+            npn = nums.ctypes.data_as(C.c_void_p)
+        check(self._L.lpbox_iterate_l2f(self._h, _as_int(i, "i"), _as_int(j, "j"), vp, stride, npn,
+                                        rets.ctypes.data_as(C.c_void_p)), "lpbox_iterate_l2f")
+        return rets
+
+    # ---- results ----
+    def get_n(self, idx=0):
+        return check(self._L.lpbox_get_n(self._h, idx), "lpbox_get_n")
+
+    def get_org_n(self, idx=0):
+        return check(self._L.lpbox_get_org_n(self._h, idx), "lpbox_get_org_n")
+
+    def get_l(self, idx=0):
+        return check(self._L.lpbox_get_l(self._h, idx), "lpbox_get_l")
+
+    def get_iter(self, idx=0):
+        return check(self._L.lpbox_get_iter(self._h, idx), "lpbox_get_iter")
+
+    def get_x_iters_2d(self, ws, idx=0):
+        ws = _as_int(ws, "ws")
+        rows = check(self._L.lpbox_get_x_iters(self._h, idx, ws, None), "lpbox_get_x_iters")
+        out = np.zeros((rows, ws), np.float64)
+        if rows and ws:
+            check(self._L.lpbox_get_x_iters(self._h, idx, ws, out.ctypes.data_as(C.c_void_p)), "lpbox_get_x_iters")
+        return out
+
+    def get_x_sol(self, idx=0):
+        out = np.zeros(self.get_org_n(idx), np.float64)
+        check(self._L.lpbox_get_x_sol(self._h, idx, out), "lpbox_get_x_sol")
+        return out
+
+    def get_final_x_sol(self, idx=0):
+        out = np.zeros(self.get_org_n(idx), np.float64)
+        k = check(self._L.lpbox_get_final_x_sol(self._h, idx, out), "lpbox_get_final_x_sol")
+        return out[:k].copy()
+
+    def cal_obj(self, idx=0):
+        v = C.c_double()
+        check(self._L.lpbox_cal_obj(self._h, idx, C.byref(v)), "lpbox_cal_obj")
+        return v.value
+
+    def cur_bin_obj(self, idx=0):
+        v = C.c_double()
+        check(self._L.lpbox_cur_bin_obj(self._h, idx, C.byref(v)), "lpbox_cur_bin_obj")
+        return v.value
+
+    def check_infeasible_lpbox(self, idx=0):
+        return check(self._L.lpbox_check_infeasible_lpbox(self._h, idx), "lpbox_check_infeasible_lpbox")
+
+    def check_infeasible_l2f(self, idx=0):
+        return check(self._L.lpbox_check_infeasible_l2f(self._h, idx), "lpbox_check_infeasible_l2f")
+
+    # ---- extensions ----
+    def config(self):
+        t, e, l = C.c_int(), C.c_int(), C.c_int()
+        check(self._L.lpbox_get_config(self._h, C.byref(t), C.byref(e), C.byref(l)), "lpbox_get_config")
+        return dict(threads=t.value, elems_per_thread=e.value, lds_bytes=l.value)
+
+    def counters(self, idx=0):
+        o, p = C.c_longlong(), C.c_longlong()
+        check(self._L.lpbox_get_counters(self._h, idx, C.byref(o), C.byref(p)), "lpbox_get_counters")
+        return o.value, p.value
+
+    def stop(self, idx=0):
+        r, p = C.c_int(), C.c_int()
+        check(self._L.lpbox_get_stop(self._h, idx, C.byref(r), C.byref(p)), "lpbox_get_stop")
+        return r.value, p.value
+
+    def kernel_time(self, reset=False):
+        ms, n = C.c_double(), C.c_longlong()
+        check(self._L.lpbox_kernel_time(self._h, C.byref(ms), C.byref(n), int(bool(reset))), "lpbox_kernel_time")
+        return ms.value, n.value
+
+    def debug_vec(self, name, idx=0):
+        cap = max(self.get_org_n(idx), self.get_l(idx))
+        out = np.zeros(cap, np.float64)
+        k = check(self._L.lpbox_debug_get_vec(self._h, idx, name.encode(), out, cap), "lpbox_debug_get_vec")
+        return out[:k].copy()
+
+    def debug_scalar(self, name, idx=0):
+        v = C.c_double()
+        check(self._L.lpbox_debug_get_scalar(self._h, idx, name.encode(), C.byref(v)), "lpbox_debug_get_scalar")
+        return v.value
+
+
+class PyLPboxADMMsolver:
+    """Same surface as the reference's `cdef class PyLPboxADMMsolver` (LP pyx:7-76), one instance per object.
+
+    print_info: 0 quiet, 1 print fix sizes (LPcpp:1188-1190).  Set `verbose = True` to echo the reference's
+    stdout messages (constructor banner LPcpp:478, stop reasons :935/:984, fix summary :1333).
+    `data_root` (or the LPBOX_DATA_ROOT environment variable) replaces the reference's CWD-relative
+    "../cython_solver/data" (LPcpp:2451).
+    """
+
+    data_root = None
+    verbose = False
+
+    def __init__(self, print_info=0, *unused):
+        if unused:
+            # lpbox.pyx defines __cinit__ twice (:10-11, :13-14); the 1-argument form is the one every caller uses
+            raise TypeError("PyLPboxADMMsolver takes a single int (print_info)")
+        self._b = LpBatch(batch=1, print_info=_as_int(print_info, "print_info"))
+        self.print_info = int(print_info)
+        if self.verbose:
+            print("Object with fix_info is created!")
+
+    # LP pyx:16-17
+    def read_File(self, i, k, j):
+        root = self.data_root or os.environ.get("LPBOX_DATA_ROOT")
+        self._b.read_file(0, _as_int(i, "i"), _as_int(k, "k"), _as_int(j, "j"), root)
+        return None
+
+    # extension: hand the problem over in memory instead of through the instance files
+    def set_problem(self, n, l, colptr, rowidx, b, f=None):
+        self._b.set_problem(0, n, l, colptr, rowidx, b, f)
+
+    # LP pyx:19-20
+    def solve_init(self):
+        return self._b.solve_init()
+
+    # LP pyx:22-23
+    def solve_iter(self, i, j):
+        ret = int(self._b.solve_iter(i, j)[0])
+        self._echo_stop(plain=True)
+        return ret
+
+    # LP pyx:25-26
+    def cal_Obj(self):
+        return self._b.cal_obj(0)
+
+    # LP pyx:28-29
+    def get_curBinObj(self):
+        return self._b.cur_bin_obj(0)
+
+    # LP pyx:31-32
+    def solve_iter_l2f(self, i, j, vec, num):
+        vec = np.ascontiguousarray(vec, np.float64).ravel()
+        num = _as_int(num, "num")
+        n_before = self._b.get_n(0)
+        if num != 0 and vec.shape[0] < n_before:
+            raise ValueError(f"vec has {vec.shape[0]} entries, need at least n_live = {n_before}")
+        ret = int(self._b.solve_iter_l2f(i, j, vec.reshape(1, -1), np.array([num], np.int32))[0])
+        if num != 0 and self.verbose:
+            print("Iter: %d; Fixed %d Elements; Totally Fixed %d Elements; Left %d Elements; Sum_fix_obj: %f" % (
+                int(i), num, self._b.get_org_n(0) - (n_before - num), n_before - num,
+                self._b.debug_scalar("sum_fix_obj", 0)))
+        self._echo_stop(plain=False)
+        return ret
+
+    # LP pyx:35-41
+    def get_x_iters_1d(self, ws):
+        ws = _as_int(ws, "ws")
+        if ws < 20:
+            raise ValueError("get_x_iters_1d reads n*20 entries (LP pyx:38-40): ws must be >= 20")
+        flat = self._b.get_x_iters_2d(ws, 0).ravel()
+        n = self._b.get_n(0)
+        return flat[: n * 20].reshape(n * 20, 1).copy()
+
+    # LP pyx:43-50
+    def get_x_iters_2d(self, ws):
+        return self._b.get_x_iters_2d(ws, 0)
+
+    # LP pyx:52-53
+    def get_n(self):
+        return self._b.get_n(0)
+
+    # LP pyx:55-56
+    def get_iter(self):
+        return self._b.get_iter(0)
+
+    # LP pyx:58-63
+    def get_x_sol(self, n=None):
+        x = self._b.get_x_sol(0)
+        n = x.shape[0] if n is None else _as_int(n, "n")
+        return x[:n].reshape(n, 1)
+
+    # LP pyx:65-70
+    def get_final_x_sol(self, n=None):
+        x = self._b.get_final_x_sol(0)
+        n = x.shape[0] if n is None else _as_int(n, "n")
+        out = np.zeros((n, 1))
+        out[: min(n, x.shape[0]), 0] = x[:n]
+        return out
+
+    # LP pyx:72-73
+    def check_infeasible_lpbox(self):
+        return self._b.check_infeasible_lpbox(0)
+
+    # LP pyx:75-76
+    def check_infeasible_l2f(self):
+        return self._b.check_infeasible_l2f(0)
+
+    # ---- extensions ----
+    @property
+    def batch(self):
+        return self._b
+
+    def _echo_stop(self, plain):
+        if not self.verbose:
+            return
+        reason, p1 = self._b.stop(0)
+        it = (p1 - 1) if plain else self._b.get_iter(0)
+        if reason == 1:
+            c = max(self._b.debug_scalar("cvg1"), self._b.debug_scalar("cvg2"))
+            print(("Stop because y1_y2. iter: %d, stop_threshold: %.6f" if plain else
+                   "Stop becuase y1_y2. iter: %d, stop_threshold: %.6f") % (it, c))
+        elif reason == 2:
+            print(("Stop because obj_std. iter: %d, std_threshold: %.6f" if plain else
+                   "Stop because std_obj. iter: %d, std_threshold: %.6f") % (it, self._b.debug_scalar("std_obj")))

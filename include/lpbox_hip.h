@@ -1,0 +1,109 @@
+/*
+ * lpbox_hip.h -- C-ABI of liblpbox_hip.so, the MI355X (gfx950) Lp-Box ADMM inner solver.
+ *
+ * This is the drop-in boundary for the reference's Cython solver API.  Each entry point names the
+ * reference interface it replaces ("LP pxd" = LinerProgramming/LinearProgramming/cython_solver/LPboxADMMsolver.pxd,
+ * "LP pyx" = .../cython_solver/lpbox.pyx, "LPcpp" = .../cython_solver/LPboxADMMsolver.cpp,
+ * "SEG pxd/pyx/cpp" = Segmentation/Segmentation/cython/src/{LPboxADMMsolver.pxd,lpbox.pyx,LPboxADMMsolver.cpp}).
+ *
+ * Conventions
+ *  - plain C types only: pointers + sizes, caller-owned buffers, no ownership ever returned
+ *    (the reference returns leaked `new double[]`, LPcpp:1620,1657,1677 -- not reproduced);
+ *  - every function returns an int status unless documented otherwise: 0 (or a non-negative
+ *    payload) = ok, < 0 = LPBOX_E_* error; lpbox_last_error() gives the text.  Nothing calls exit();
+ *  - one handle owns one HIP stream; calls on a handle are synchronous and must be serialised by the
+ *    caller; different handles may be used from different host threads;
+ *  - all arithmetic is fp64 (LPh:16), indices int32 on the API, uint16 inside the kernels;
+ *  - there is NO CPU fallback: without a HIP device every compute call fails with LPBOX_E_NODEVICE.
+ */
+#ifndef LPBOX_HIP_H
+#define LPBOX_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LPBOX_OK            0
+#define LPBOX_E_BADHANDLE  -1
+#define LPBOX_E_BADARG     -2
+#define LPBOX_E_STATE      -3   /* call order violated (e.g. iterate before init) */
+#define LPBOX_E_IO         -4   /* instance file missing / unparsable (LPcpp:2409-2412 would exit(-1)) */
+#define LPBOX_E_HIP        -5   /* HIP runtime error, text in lpbox_last_error() */
+#define LPBOX_E_NODEVICE   -6
+#define LPBOX_E_UNSUPPORTED -7  /* instance outside what the persistent kernels hold on-chip */
+#define LPBOX_E_NOMEM      -8
+
+#define LPBOX_FLAVOUR_LP   0    /* min b'x  s.t. Ex<=f, x in {0,1}^n      (LPcpp) */
+#define LPBOX_FLAVOUR_SEG  1    /* min x'Ax + b'x, x in {0,1}^n           (SEGcpp) */
+
+typedef struct lpbox_solver lpbox_t;      /* one or a batch of independent instances on one GPU */
+
+/* ---- library / device ---------------------------------------------------------------------- */
+const char *lpbox_version(void);
+const char *lpbox_last_error(void);               /* thread-local text of the last failure */
+int  lpbox_device_count(void);                    /* number of HIP devices visible (0 if none) */
+int  lpbox_set_device(int device);                /* device used by handles created afterwards on this thread */
+
+/* ---- object life-cycle ---------------------------------------------------------------------- */
+/* LP pxd:6-8 / LP pyx:13-14  `LPboxADMMsolver(int print_info)`  (SEG pyx:14-15 for flavour SEG).
+ * batch = number of independent instances held by the handle (1 = the reference's single object). */
+lpbox_t *lpbox_create(int flavour, int batch, int print_info);
+void     lpbox_destroy(lpbox_t *h);
+
+/* ---- problem input (instance index idx in [0,batch)) ------------------------------------------ */
+/* What readFile leaves in the object (LPcpp:2446-2545): E (l x n) column-major, row indices ascending in a
+ * column, all stored values must be 1.0 (vals == NULL means all ones; anything else -> LPBOX_E_UNSUPPORTED),
+ * b ALREADY NEGATED (LPcpp:2520), f (NULL means all ones, LPcpp:2522). */
+int lpbox_set_problem_lp(lpbox_t *h, int idx, int n, int l, int nnz, const int *colptr, const int *rowidx,
+                         const double *vals, const double *b, const double *f);
+/* LP pxd:9 `void readFile(int,int,int)` (LPcpp:2446-2545) with the two paths explicit; k as in the reference. */
+int lpbox_read_files_lp(lpbox_t *h, int idx, const char *path_C, const char *path_b, int k);
+/* LP pxd:9 verbatim: instance i, k items, j bids under `<root>/instance/<k>_<j>/instance_<i>_{C,b}.txt`;
+ * root NULL = the reference's "../cython_solver/data" relative to the CWD (LPcpp:2451). */
+int lpbox_read_file(lpbox_t *h, int idx, const char *root, int i, int k, int j);
+
+/* ---- solver (whole batch per call) ------------------------------------------------------------ */
+/* LP pxd:10 `int ADMM_lp_iters_init()` (LPcpp:489-763).  Returns 1 like the reference. */
+int lpbox_init(lpbox_t *h);
+/* LP pxd:11 `int ADMM_lp_iters(int,int)` (LPcpp:766-1095).  rets[batch] receives each instance's return value
+ * (1 iff stopped by the objective-std test, LPcpp:977-979); may be NULL.  Function returns rets[0]. */
+int lpbox_iterate(lpbox_t *h, int iter_start, int iter_end, int *rets);
+/* LP pxd:13 `int ADMM_lp_iters_l2f(int,int,double*,int)` (LPcpp:1098-1574).
+ * vec: for instance idx the fix vector starts at vec + idx*vec_stride and holds >= n_live entries in {1,0,-1}
+ * over the CURRENT live variables; nums[idx] = count of non -1 entries (0 = ignore vec, as LPcpp:1124).
+ * rets[batch] as above (1 = converged / all fixed / PCG broke down).  Function returns rets[0]. */
+int lpbox_iterate_l2f(lpbox_t *h, int iter_start, int iter_end, const double *vec, long vec_stride,
+                      const int *nums, int *rets);
+
+/* ---- results (instance idx) ------------------------------------------------------------------- */
+int lpbox_get_n(lpbox_t *h, int idx);                         /* LP pxd:15 get_n(): live variables          */
+int lpbox_get_org_n(lpbox_t *h, int idx);                     /* SEG pxd get_org_n(); original n            */
+int lpbox_get_l(lpbox_t *h, int idx);
+int lpbox_get_iter(lpbox_t *h, int idx);                      /* LP pxd:16 get_iter() (LPh:347-349)         */
+/* LP pxd:14 `double* get_x_iters_d(int)` (LPcpp:1616-1627): out[rows*ws] row-major, rows = n_live of the last
+ * l2f call; returns rows.  out may be NULL to query rows. */
+int lpbox_get_x_iters(lpbox_t *h, int idx, int ws, double *out);
+int lpbox_get_x_sol(lpbox_t *h, int idx, double *out);        /* LP pxd:17 (LPcpp:1648-1665): out[org_n] in {0,1} */
+int lpbox_get_final_x_sol(lpbox_t *h, int idx, double *out);  /* LP pxd:18 (LPcpp:1668-1685): raw live x, returns its length */
+int lpbox_cal_obj(lpbox_t *h, int idx, double *out);          /* LP pxd:12 cal_obj() (LPcpp:1630-1642)      */
+int lpbox_cur_bin_obj(lpbox_t *h, int idx, double *out);      /* LP pxd:19 get_curBinObj() (LPcpp:1644-1646) */
+int lpbox_check_infeasible_lpbox(lpbox_t *h, int idx);        /* LP pxd:20 (LPcpp:1577-1591): count, >= 0   */
+int lpbox_check_infeasible_l2f(lpbox_t *h, int idx);          /* LP pxd:21 (LPcpp:1593-1612): count, >= 0   */
+
+/* ---- extensions beyond the pxd (batching, measurement, inspection) ---------------------------- */
+/* Workgroup geometry picked for the batch: threads per instance (the reduction tree depends on it). */
+int lpbox_get_config(lpbox_t *h, int *threads, int *elems_per_thread, int *lds_bytes);
+/* Counters accumulated since init: outer ADMM iterations and PCG iterations of instance idx (LPcpp:894 maxiter). */
+int lpbox_get_counters(lpbox_t *h, int idx, long long *outer_iters, long long *pcg_iters);
+/* Which stop fired in the last call: 0 none, 1 y1_y2, 2 obj_std, 3 PCG alpha<0, 4 all fixed; and iter+1 of the last plain call (LPcpp:1081). */
+int lpbox_get_stop(lpbox_t *h, int idx, int *reason, int *plain_iter_plus1);
+/* Device time (ms, HIP events on the handle's stream) and launch count of the ADMM window kernel since the last reset. */
+int lpbox_kernel_time(lpbox_t *h, double *ms_total, long long *launches, int reset);
+/* Copy a named device state vector of instance idx ("x","z1","z2","z4","f","pd","b"); returns its length. */
+int lpbox_debug_get_vec(lpbox_t *h, int idx, const char *name, double *out, int cap);
+int lpbox_debug_get_scalar(lpbox_t *h, int idx, const char *name, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
