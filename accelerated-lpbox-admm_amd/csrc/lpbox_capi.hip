@@ -40,6 +40,8 @@ struct LpInstance {
     int n = 0, l = 0, nnz = 0;
     std::vector<int> colptr, rowidx;   // CSC of E, as read (LPcpp:2416-2444)
     std::vector<int> rowptr, colidx;   // CSR of the same matrix
+    std::vector<int> cpos, cperm;      // storage layout: variable j sits at position cpos[j]; cperm[pos] = j
+    std::vector<int> rowG;             // lanes that share the sum of row r (1,2,4,8)
     std::vector<double> b, f_org;
     // early-fix bookkeeping (LPcpp:1192-1206): original index of each live variable, in compact order
     std::vector<int> left_idx;
@@ -76,10 +78,11 @@ struct lpbox_solver {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double kernel_ms = 0.0;
     long long launches = 0;
-    DevBuf<int> csr_ptr, csc_ptr, isc, ctl, left_idx, xi_rows;
-    DevBuf<uint16_t> csr_col, csc_row;
+    DevBuf<int> rs_ptr, cs_ptr, isc, ctl, left_idx, xi_rows;
+    DevBuf<uint16_t> rs_col, cs_row, rid, rmeta;
     DevBuf<double> x, z1, z2, b, pd, z4, f, f_org, dsc, hist, dctl, c1_init, xhist, xi_out;
-    DevBuf<uint8_t> live, newfix;
+    DevBuf<uint8_t> live, newfix, live_init;
+    DevBuf<unsigned long long> stamps;
     int ws_cap = 0;        // columns of the current xhist staging buffer
     int last_ws = 0;       // window length of the last l2f call
     bool xi_valid = false;
@@ -91,10 +94,10 @@ struct lpbox_solver {
     LpBatchDev dev() const {
         LpBatchDev d;
         d.B = B; d.NS = NS; d.LS = LS; d.ZS = ZS;
-        d.csr_ptr = csr_ptr.p; d.csr_col = csr_col.p; d.csc_ptr = csc_ptr.p; d.csc_row = csc_row.p;
+        d.rs_ptr = rs_ptr.p; d.rs_col = rs_col.p; d.cs_ptr = cs_ptr.p; d.cs_row = cs_row.p; d.rid = rid.p; d.rmeta = rmeta.p;
         d.x = x.p; d.z1 = z1.p; d.z2 = z2.p; d.b = b.p; d.pd = pd.p; d.live = live.p; d.newfix = newfix.p;
         d.z4 = z4.p; d.f = f.p; d.dsc = dsc.p; d.isc = isc.p; d.hist = hist.p;
-        d.ctl = ctl.p; d.dctl = dctl.p; d.xhist = xhist.p; d.ws_cap = ws_cap;
+        d.ctl = ctl.p; d.dctl = dctl.p; d.xhist = xhist.p; d.ws_cap = ws_cap; d.stamps = stamps.p;
         return d;
     }
 };
@@ -134,25 +137,31 @@ int finalize(lpbox_t *h) {
     if (rc) return rc;
     int nmax = 0, lmax = 0, zmax = 0;
     for (auto &I : h->inst) { nmax = std::max(nmax, I.n); lmax = std::max(lmax, I.l); zmax = std::max(zmax, I.nnz); }
-    if (nmax > 65535 || lmax > 65535) return fail(LPBOX_E_UNSUPPORTED, "n or l exceeds the uint16 index range of the on-chip kernel");
-    h->NS = (nmax + 7) & ~7; h->LS = (lmax + 7) & ~7; h->ZS = (zmax + 7) & ~7;
-    int T = 512;
-    if (const char *e = getenv("LPBOX_LP_THREADS")) { int v = atoi(e); if (v == 256 || v == 512 || v == 1024) T = v; }
+    if (nmax > 65534 || lmax > 65534) return fail(LPBOX_E_UNSUPPORTED, "n or l exceeds the uint16 index range of the on-chip kernel");
+    // workgroup geometry: 8 wavefronts (two per SIMD of the CU) with as few slots per thread as the instance allows; the
+    // largest instances use 4 wavefronts x 8 slots so that each lane may take the whole 512-entry register file.
+    // LPBOX_LP_THREADS overrides (tuning only).
     const int big = std::max(nmax, lmax);
-    int EPT = (big + T - 1) / T;
-    EPT = EPT <= 1 ? 1 : (EPT <= 2 ? 2 : 4);
-    if ((long)T * EPT < big && T < 1024) { T = 1024; EPT = (big + T - 1) / T; EPT = EPT <= 1 ? 1 : (EPT <= 2 ? 2 : 4); }
+    int T = big > 1024 ? 256 : 512;
+    if (const char *e = getenv("LPBOX_LP_THREADS")) { int v = atoi(e); if (v == 256 || v == 512) T = v; }
+    const int max_ept = T == 256 ? 8 : 2;
+    int EPT = 1;
+    while (EPT < max_ept && (long)T * EPT < big) EPT *= 2;
+    if ((long)T * EPT < big && T == 512) { T = 256; EPT = 1; while (EPT < 8 && (long)T * EPT < big) EPT *= 2; }
     if ((long)T * EPT < big)
         return fail(LPBOX_E_UNSUPPORTED, "instance with max(n,l)=%d exceeds the on-chip kernel's %d register slots", big, T * EPT);
     h->T = T; h->EPT = EPT;
+    h->NS = T * EPT;                       // storage positions / row-task slots per instance
+    h->LS = (lmax + 7) & ~7; h->ZS = (zmax + 7) & ~7;
     h->lds = lp_window_lds_bytes(T, h->NS, h->LS, h->ZS);
     if (h->lds > 160 * 1024) return fail(LPBOX_E_UNSUPPORTED, "instance needs %zu B of LDS (> 160 KiB per CU)", h->lds);
 
     if (!h->stream) HIPCHK(hipStreamCreate(&h->stream));
     if (!h->ev0) { HIPCHK(hipEventCreate(&h->ev0)); HIPCHK(hipEventCreate(&h->ev1)); }
     const size_t B = h->B, NS = h->NS, LS = h->LS, ZS = h->ZS;
-    HIPCHK(h->csr_ptr.alloc(B * (LS + 1))); HIPCHK(h->csc_ptr.alloc(B * (NS + 1)));
-    HIPCHK(h->csr_col.alloc(B * ZS)); HIPCHK(h->csc_row.alloc(B * ZS));
+    HIPCHK(h->rs_ptr.alloc(B * (NS + 1))); HIPCHK(h->cs_ptr.alloc(B * (NS + 1)));
+    HIPCHK(h->rs_col.alloc(B * ZS)); HIPCHK(h->cs_row.alloc(B * ZS)); HIPCHK(h->rid.alloc(B * NS)); HIPCHK(h->rmeta.alloc(B * NS));
+    HIPCHK(h->live_init.alloc(B * NS));
     HIPCHK(h->x.alloc(B * NS)); HIPCHK(h->z1.alloc(B * NS)); HIPCHK(h->z2.alloc(B * NS));
     HIPCHK(h->b.alloc(B * NS)); HIPCHK(h->pd.alloc(B * NS));
     HIPCHK(h->live.alloc(B * NS)); HIPCHK(h->newfix.alloc(B * NS));
@@ -160,25 +169,101 @@ int finalize(lpbox_t *h) {
     HIPCHK(h->dsc.alloc(B * ND_COUNT)); HIPCHK(h->isc.alloc(B * NI_COUNT)); HIPCHK(h->hist.alloc(B * LP_HIST));
     HIPCHK(h->ctl.alloc(B * 4)); HIPCHK(h->dctl.alloc(B)); HIPCHK(h->c1_init.alloc(B));
     HIPCHK(h->left_idx.alloc(B * NS)); HIPCHK(h->xi_rows.alloc(B));
+#ifdef LPBOX_STAMPS
+    HIPCHK(h->stamps.alloc(B * 16)); HIPCHK(hipMemset(h->stamps.p, 0, B * 16 * sizeof(unsigned long long)));
+#endif
 
-    std::vector<int> h_csr_ptr(B * (LS + 1), 0), h_csc_ptr(B * (NS + 1), 0), h_isc(B * NI_COUNT, 0);
-    std::vector<uint16_t> h_csr_col(B * ZS, 0), h_csc_row(B * ZS, 0);
+    std::vector<int> h_rs_ptr(B * (NS + 1), 0), h_cs_ptr(B * (NS + 1), 0), h_isc(B * NI_COUNT, 0);
+    std::vector<uint16_t> h_rs_col(B * ZS, 0), h_cs_row(B * ZS, 0), h_rid(B * NS, 0xFFFF), h_rmeta(B * NS, 0x10);
+    std::vector<uint8_t> h_live(B * NS, 0);
     std::vector<double> h_b(B * NS, 0.0), h_f(B * LS, 0.0), h_c1(B, 0.0);
+    const bool nosort = getenv("LPBOX_LP_NOSORT") != nullptr;
+    const bool nosplit = getenv("LPBOX_LP_NOSPLIT") != nullptr;
+    const int W = h->T / 64;
+    // block b of 64 consecutive (sorted) items -> storage slot: slots are dealt to the waves in snake order so that every
+    // wave receives a similar amount of gather work
+    auto block_base = [&](int blk) {
+        const int slot = blk / W, r = blk % W;
+        const int wv = (slot & 1) ? (W - 1 - r) : r;
+        return slot * h->T + wv * 64;
+    };
     for (size_t i = 0; i < B; i++) {
-        const LpInstance &I = h->inst[i];
-        for (int r = 0; r <= I.l; r++) h_csr_ptr[i * (LS + 1) + r] = I.rowptr[r];
-        for (int c = 0; c <= I.n; c++) h_csc_ptr[i * (NS + 1) + c] = I.colptr[c];
-        for (int k = 0; k < I.nnz; k++) { h_csr_col[i * ZS + k] = (uint16_t)I.colidx[k]; h_csc_row[i * ZS + k] = (uint16_t)I.rowidx[k]; }
-        for (int j = 0; j < I.n; j++) h_b[i * NS + j] = I.b[j];
+        LpInstance &I = h->inst[i];
+        // ---- columns: variable j -> storage position cpos[j], by decreasing column length (stable) ----
+        I.cperm.resize(I.n); I.cpos.resize(I.n);
+        for (int j = 0; j < I.n; j++) I.cperm[j] = j;
+        if (!nosort)
+            std::stable_sort(I.cperm.begin(), I.cperm.end(), [&](int a, int c) {
+                return I.colptr[a + 1] - I.colptr[a] > I.colptr[c + 1] - I.colptr[c]; });
+        std::vector<int> var_of_pos(NS, -1);
+        for (int q = 0; q < I.n; q++) {
+            const int p = nosort ? q : block_base(q / 64) + q % 64;
+            I.cpos[I.cperm[q]] = p;
+            var_of_pos[p] = I.cperm[q];
+        }
+        int k = 0;
+        for (size_t p = 0; p < NS; p++) {
+            h_cs_ptr[i * (NS + 1) + p] = k;
+            const int j = var_of_pos[p];
+            if (j < 0) continue;
+            for (int e = I.colptr[j]; e < I.colptr[j + 1]; e++) h_cs_row[i * ZS + k++] = (uint16_t)I.rowidx[e];
+            h_b[i * NS + p] = I.b[j];
+            h_live[i * NS + p] = 1;
+        }
+        h_cs_ptr[i * (NS + 1) + NS] = k;
+        // ---- rows: G lanes share a row so that no lane walks more than ~L entries; lane g takes entries g, g+G, ... ----
+        I.rowG.assign(I.l, 1);
+        if (!nosplit) {
+            for (int Lt = 4; Lt <= 65536; Lt++) {
+                long tot = 0;
+                for (int r = 0; r < I.l; r++) {
+                    const int m = I.rowptr[r + 1] - I.rowptr[r];
+                    int G = 1;
+                    while (G < 8 && (m + G - 1) / G > Lt) G *= 2;
+                    I.rowG[r] = G; tot += G;
+                }
+                if (tot <= (long)NS) break;
+            }
+        }
+        std::vector<int> rorder(I.l);
+        for (int r = 0; r < I.l; r++) rorder[r] = r;
+        auto chain = [&](int r) { return (I.rowptr[r + 1] - I.rowptr[r] + I.rowG[r] - 1) / I.rowG[r]; };
+        if (!nosort)
+            std::stable_sort(rorder.begin(), rorder.end(), [&](int a, int c) {
+                if (I.rowG[a] != I.rowG[c]) return I.rowG[a] > I.rowG[c];
+                return chain(a) > chain(c); });
+        else
+            std::stable_sort(rorder.begin(), rorder.end(), [&](int a, int c) { return I.rowG[a] > I.rowG[c]; });
+        struct Task { int row, g, G; };
+        std::vector<Task> task_of_slot(NS, Task{-1, 0, 1});
+        int q = 0;
+        for (int r : rorder)
+            for (int g = 0; g < I.rowG[r]; g++, q++) {
+                const int tp = nosort ? q : block_base(q / 64) + q % 64;
+                task_of_slot[tp] = Task{r, g, I.rowG[r]};
+            }
+        k = 0;
+        for (size_t tp = 0; tp < NS; tp++) {
+            h_rs_ptr[i * (NS + 1) + tp] = k;
+            const Task &t = task_of_slot[tp];
+            if (t.row < 0) continue;
+            for (int e = I.rowptr[t.row] + t.g; e < I.rowptr[t.row + 1]; e += t.G) h_rs_col[i * ZS + k++] = (uint16_t)I.cpos[I.colidx[e]];
+            h_rid[i * NS + tp] = (uint16_t)t.row;
+            h_rmeta[i * NS + tp] = (uint16_t)((t.G << 4) | t.g);
+        }
+        h_rs_ptr[i * (NS + 1) + NS] = k;
         for (int r = 0; r < I.l; r++) h_f[i * LS + r] = I.f_org[r];
         h_isc[i * NI_COUNT + NI_N] = I.n; h_isc[i * NI_COUNT + NI_L] = I.l; h_isc[i * NI_COUNT + NI_NNZ] = I.nnz;
         h_isc[i * NI_COUNT + NI_ACTIVE] = 1;
         h_c1[i] = std::pow((double)I.n, 1.0 / 2);     // std::pow(n, 1.0/p), p = projection_lp = 2 (LPcpp:427,503)
     }
-    HIPCHK(hipMemcpy(h->csr_ptr.p, h_csr_ptr.data(), h_csr_ptr.size() * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->csc_ptr.p, h_csc_ptr.data(), h_csc_ptr.size() * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->csr_col.p, h_csr_col.data(), h_csr_col.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->csc_row.p, h_csc_row.data(), h_csc_row.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->rmeta.p, h_rmeta.data(), h_rmeta.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->live_init.p, h_live.data(), h_live.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->rs_ptr.p, h_rs_ptr.data(), h_rs_ptr.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->cs_ptr.p, h_cs_ptr.data(), h_cs_ptr.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->rs_col.p, h_rs_col.data(), h_rs_col.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->cs_row.p, h_cs_row.data(), h_cs_row.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->rid.p, h_rid.data(), h_rid.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->b.p, h_b.data(), h_b.size() * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->f_org.p, h_f.data(), h_f.size() * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->isc.p, h_isc.data(), h_isc.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -238,16 +323,25 @@ int set_instance(lpbox_t *h, int idx, int n, int l, int nnz, const int *colptr, 
     return LPBOX_OK;
 }
 
-int fetch_vec(lpbox_t *h, const double *pool, size_t stride, int idx, int len, std::vector<double> &out) {
+// n-vectors come back in ORIGINAL variable order (by_var = true undoes the storage permutation); l-vectors are stored by row id
+int fetch_vec(lpbox_t *h, const double *pool, size_t stride, int idx, int len, std::vector<double> &out, bool by_var = true) {
     out.resize(len);
     if (len == 0) return LPBOX_OK;
-    HIPCHK(hipMemcpy(out.data(), pool + (size_t)idx * stride, sizeof(double) * (size_t)len, hipMemcpyDeviceToHost));
+    const size_t cnt = by_var ? (size_t)h->NS : (size_t)len;      // n-vectors are stored by position (NS slots incl. holes)
+    std::vector<double> tmp(cnt);
+    HIPCHK(hipMemcpy(tmp.data(), pool + (size_t)idx * stride, sizeof(double) * cnt, hipMemcpyDeviceToHost));
+    const LpInstance &I = h->inst[idx];
+    if (by_var) for (int j = 0; j < len; j++) out[j] = tmp[I.cpos[j]];
+    else out.swap(tmp);
     return LPBOX_OK;
 }
 
 int fetch_live(lpbox_t *h, int idx, std::vector<uint8_t> &out) {
-    out.resize(h->inst[idx].n);
-    HIPCHK(hipMemcpy(out.data(), h->live.p + (size_t)idx * h->NS, out.size(), hipMemcpyDeviceToHost));
+    const LpInstance &I = h->inst[idx];
+    std::vector<uint8_t> tmp(h->NS);
+    out.resize(I.n);
+    HIPCHK(hipMemcpy(tmp.data(), h->live.p + (size_t)idx * h->NS, tmp.size(), hipMemcpyDeviceToHost));
+    for (int j = 0; j < I.n; j++) out[j] = tmp[I.cpos[j]];
     return LPBOX_OK;
 }
 
@@ -287,11 +381,11 @@ void lpbox_destroy(lpbox_t *h) {
     if (!h) return;
     if (h->finalized) (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    h->csr_ptr.release(); h->csc_ptr.release(); h->isc.release(); h->ctl.release(); h->left_idx.release(); h->xi_rows.release();
-    h->csr_col.release(); h->csc_row.release();
+    h->rs_ptr.release(); h->cs_ptr.release(); h->isc.release(); h->ctl.release(); h->left_idx.release(); h->xi_rows.release();
+    h->rs_col.release(); h->cs_row.release(); h->rid.release(); h->rmeta.release(); h->live_init.release();
     h->x.release(); h->z1.release(); h->z2.release(); h->b.release(); h->pd.release(); h->z4.release(); h->f.release();
     h->f_org.release(); h->dsc.release(); h->hist.release(); h->dctl.release(); h->c1_init.release(); h->xhist.release();
-    h->xi_out.release(); h->live.release(); h->newfix.release();
+    h->xi_out.release(); h->live.release(); h->newfix.release(); h->stamps.release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -374,7 +468,7 @@ int lpbox_init(lpbox_t *h) {
     }
     h->xi_valid = false;
     HIPCHK(hipMemsetAsync(h->ctl.p, 0, (size_t)h->B * 4 * sizeof(int), h->stream));
-    HIPCHK(lp_launch_init(h->dev(), h->T, h->EPT, h->f_org.p, h->c1_init.p, h->stream));
+    HIPCHK(lp_launch_init(h->dev(), h->T, h->EPT, h->f_org.p, h->c1_init.p, h->live_init.p, h->stream));
     rc = refresh_scalars(h);
     if (rc) return rc;
     h->inited = true;
@@ -436,8 +530,8 @@ int lpbox_iterate_l2f(lpbox_t *h, int iter_start, int iter_end, const double *ve
             keep.reserve(n_live - num);
             for (int q = 0; q < n_live; q++) {
                 const int org = I.left_idx[q];
-                if (v[q] == 1) h_newfix[i * NS + org] = 2;
-                else if (v[q] == 0) h_newfix[i * NS + org] = 1;
+                if (v[q] == 1) h_newfix[i * NS + I.cpos[org]] = 2;
+                else if (v[q] == 0) h_newfix[i * NS + I.cpos[org]] = 1;
                 else keep.push_back(org);
             }
             I.left_idx.swap(keep);
@@ -447,7 +541,7 @@ int lpbox_iterate_l2f(lpbox_t *h, int iter_start, int iter_end, const double *ve
         I.xi_rows = n_live - num;                                           // x_iters = Zero(n - fix_num, 500), :1113
         I.xi_left_idx = I.left_idx;
         h_rows[i] = I.xi_rows;
-        for (int q = 0; q < I.xi_rows; q++) h_left[i * NS + q] = I.left_idx[q];
+        for (int q = 0; q < I.xi_rows; q++) h_left[i * NS + q] = I.cpos[I.left_idx[q]];   // storage position of the q-th live variable
     }
     if (ws > 0 && (h->ws_cap < ws || !h->xhist.p)) {
         HIPCHK(hipStreamSynchronize(h->stream));
@@ -616,6 +710,28 @@ int lpbox_get_config(lpbox_t *h, int *threads, int *elems_per_thread, int *lds_b
     return LPBOX_OK;
 }
 
+int lpbox_get_layout(lpbox_t *h, int idx, int *pos_of_var) {
+    int rc = check_idx(h, idx);
+    if (rc) return rc;
+    rc = finalize(h);
+    if (rc) return rc;
+    if (!pos_of_var) return fail(LPBOX_E_BADARG, "null output");
+    const LpInstance &I = h->inst[idx];
+    for (int j = 0; j < I.n; j++) pos_of_var[j] = I.cpos[j];
+    return I.n;
+}
+
+int lpbox_get_row_split(lpbox_t *h, int idx, int *lanes_of_row) {
+    int rc = check_idx(h, idx);
+    if (rc) return rc;
+    rc = finalize(h);
+    if (rc) return rc;
+    if (!lanes_of_row) return fail(LPBOX_E_BADARG, "null output");
+    const LpInstance &I = h->inst[idx];
+    for (int r = 0; r < I.l; r++) lanes_of_row[r] = I.rowG[r];
+    return I.l;
+}
+
 int lpbox_get_counters(lpbox_t *h, int idx, long long *outer_iters, long long *pcg_iters) {
     int rc = check_idx(h, idx);
     if (rc) return rc;
@@ -649,14 +765,14 @@ int lpbox_debug_get_vec(lpbox_t *h, int idx, const char *name, double *out, int 
     rc = use_device(h);
     if (rc) return rc;
     const LpInstance &I = h->inst[idx];
-    const double *pool = nullptr; size_t stride = h->NS; int len = I.n;
+    const double *pool = nullptr; size_t stride = h->NS; int len = I.n; bool by_var = true;
     if (!strcmp(name, "x")) pool = h->x.p;
     else if (!strcmp(name, "z1")) pool = h->z1.p;
     else if (!strcmp(name, "z2")) pool = h->z2.p;
     else if (!strcmp(name, "b")) pool = h->b.p;
     else if (!strcmp(name, "pd")) pool = h->pd.p;
-    else if (!strcmp(name, "z4")) { pool = h->z4.p; stride = h->LS; len = I.l; }
-    else if (!strcmp(name, "f")) { pool = h->f.p; stride = h->LS; len = I.l; }
+    else if (!strcmp(name, "z4")) { pool = h->z4.p; stride = h->LS; len = I.l; by_var = false; }
+    else if (!strcmp(name, "f")) { pool = h->f.p; stride = h->LS; len = I.l; by_var = false; }
     else if (!strcmp(name, "live")) {
         std::vector<uint8_t> live;
         if ((rc = fetch_live(h, idx, live))) return rc;
@@ -666,9 +782,18 @@ int lpbox_debug_get_vec(lpbox_t *h, int idx, const char *name, double *out, int 
     } else return fail(LPBOX_E_BADARG, "unknown vector '%s'", name);
     if (len > cap) return fail(LPBOX_E_BADARG, "buffer too small");
     std::vector<double> v;
-    if ((rc = fetch_vec(h, pool, stride, idx, len, v))) return rc;
+    if ((rc = fetch_vec(h, pool, stride, idx, len, v, by_var))) return rc;
     memcpy(out, v.data(), sizeof(double) * (size_t)len);
     return len;
+}
+
+// diagnostic build only: the 16 phase counters (shader cycles of wave 0) of instance idx from the last launch
+int lpbox_debug_get_stamps(lpbox_t *h, int idx, unsigned long long *out16) {
+    int rc = check_idx(h, idx);
+    if (rc) return rc;
+    if (!h->stamps.p) return fail(LPBOX_E_UNSUPPORTED, "library built without LPBOX_STAMPS");
+    HIPCHK(hipMemcpy(out16, h->stamps.p + (size_t)idx * 16, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return LPBOX_OK;
 }
 
 int lpbox_debug_get_scalar(lpbox_t *h, int idx, const char *name, double *out) {

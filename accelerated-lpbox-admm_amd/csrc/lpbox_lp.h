@@ -3,11 +3,11 @@
 // One 'instance' = one combinatorial-auction LP of the reference (LPcpp = LinerProgramming/LinearProgramming/
 // cython_solver/LPboxADMMsolver.cpp).  A batch keeps every per-instance array in one pool with a common
 // stride so that instance i, element j lives at pool[i*stride + j]:
-//   n-vectors (stride NS): x, z1, z2, b, pd, live, newfix          (ORIGINAL variable order, never compacted:
+//   n-vectors (stride NS): x, z1, z2, b, pd, live, newfix          (storage = position order, never compacted:
 //                                                                   early fixing is a mask)
 //   l-vectors (stride LS): z4, f
-//   indices:   csr_ptr (LS+1) / csr_col (ZS)  rows of E  -> E*v   gathers
-//              csc_ptr (NS+1) / csc_row (ZS)  cols of E  -> E^T*w gathers
+//   indices:   rs_ptr (LS+1) / rs_col (ZS)  rows of E  -> E*v   gathers
+//              cs_ptr (NS+1) / cs_row (ZS)  cols of E  -> E^T*w gathers
 //   scalars:   dsc[ND_*], isc[NI_*], hist[LP_HIST]
 #pragma once
 #include <hip/hip_runtime.h>
@@ -45,9 +45,12 @@ enum { LP_STOP_NONE = 0, LP_STOP_Y1Y2 = 1, LP_STOP_OBJSTD = 2, LP_STOP_PCG = 3, 
 
 struct LpBatchDev {
     int B, NS, LS, ZS;
-    // structure
-    const int *csr_ptr; const uint16_t *csr_col;
-    const int *csc_ptr; const uint16_t *csc_row;
+    // structure, in STORAGE order: variables sit at positions (columns of E sorted by decreasing length), row slots
+    // likewise hold rows by decreasing length (rid[slot] = original row id; l-vectors stay indexed by original row id)
+    const int *rs_ptr; const uint16_t *rs_col;   // row slot q: positions of its columns, ascending ORIGINAL column index
+    const int *cs_ptr; const uint16_t *cs_row;   // position p: original row ids of its column, ascending
+    const uint16_t *rid;      // row-task slot -> original row id (0xFFFF = no task)
+    const uint16_t *rmeta;    // row-task slot -> (G << 4) | g: lane g of the G lanes sharing the row
     // state
     double *x, *z1, *z2, *b, *pd;
     uint8_t *live;          // 1 = live, 0 = fixed (x then holds the fixed value)
@@ -59,12 +62,14 @@ struct LpBatchDev {
     const int *ctl; const double *dctl;
     // l2f iterate window: xhist[(inst*ws_cap + c)*NS + pos]
     double *xhist; int ws_cap;
+    unsigned long long *stamps;   // diagnostic build only (LPBOX_STAMPS): 16 phase counters per instance, else nullptr
 };
 
 // launchers (lpbox_lp_kernels.hip)
 size_t lp_window_lds_bytes(int T, int NS, int LS, int ZS);
-hipError_t lp_launch_init(const LpBatchDev &bd, int T, int EPT, const double *f_org, const double *c1_init, hipStream_t s);
+hipError_t lp_launch_init(const LpBatchDev &bd, int T, int EPT, const double *f_org, const double *c1_init,
+                          const uint8_t *live_init, hipStream_t s);
 hipError_t lp_launch_window(const LpBatchDev &bd, int T, int EPT, size_t lds, int iter_start, int iter_end, int l2f,
                             hipStream_t s);
-hipError_t lp_launch_pack_xiters(const LpBatchDev &bd, const int *left_idx, const int *rows, int ws, double *out,
+hipError_t lp_launch_pack_xiters(const LpBatchDev &bd, const int *live_pos, const int *rows, int ws, double *out,
                                  long out_stride, hipStream_t s);

@@ -3,16 +3,20 @@
 // Design (MI355X-first):
 //   * one workgroup == one LP instance, persistent over a whole window of ADMM iterations (one launch runs
 //     iterations [iter_start, iter_end) of every instance of the batch; 256 instances fill the 256 CUs);
-//   * every n- and l-vector of the algorithm lives in REGISTERS of the thread that owns the element
-//     (element pos -> thread pos % T, slot pos / T); only the three vectors that other threads must gather
-//     (p / x for E*v, E*v and f-y3 / z4 for E^T*w) are staged in LDS, together with the uint16 CSR+CSC
-//     index sets of E.  HBM is touched once per launch (state in / state out) plus the x_iters window;
-//   * all dot products / norms use one fixed reduction tree: per-thread slot sums -> 64-lane xor butterfly
-//     on DPP + v_permlane{16,32}_swap -> wave partials through LDS, added in wave order.  The CPU oracle
-//     reproduces exactly this association (oracle/lpbox_oracle.c, LPO_ORDER_GPU), which makes the kernel
-//     bit-comparable with it; sparse row sums run in ascending index order like Eigen's CSC product;
-//   * early fixing is a mask: a fixed variable keeps its register slot, is excluded from every gather and
-//     reduction by predication (it contributes +0.0) and the x-update commits `live ? x_new : x_fixed`.
+//   * every n- and l-vector of the algorithm lives in REGISTERS of the thread that owns the element; only the
+//     vectors other threads must gather (p / x for E*v; E*v, f-y3, z4 for E^T*w) are staged in LDS.
+//     HBM is touched once per launch (state in / state out) plus the x_iters window of the l2f path;
+//   * variables are stored in POSITION order (columns of E sorted by decreasing length, rows likewise) so that
+//     the 64 lanes of a wavefront walk gather lists of equal length; each thread keeps the LDS byte offsets
+//     of its own row / column in registers (loaded once per launch), so a sparse product is a burst of
+//     independent ds_read_b64 gathers followed by the additions in ascending index order -- the order Eigen's
+//     column-major product uses (LPcpp:102-108).  Lists are padded with the offset of a zero slot: adding +0.0
+//     is exact, so padding never changes a sum;
+//   * all dot products / norms use one fixed reduction tree: per-thread slot sums -> 64-lane xor butterfly on
+//     DPP + v_permlane{16,32}_swap -> wave partials through LDS, added in wave order.  The CPU oracle reproduces
+//     exactly this association (oracle/lpbox_oracle.c, LPO_ORDER_GPU) which makes the kernel bit-comparable to it;
+//   * early fixing is a mask: a fixed variable keeps its register slot, contributes +0.0 to every gather and
+//     reduction by predication, and the x-update commits `live ? x_new : x_fixed` (branchless).
 //
 // Reference citations: LPcpp = LinerProgramming/LinearProgramming/cython_solver/LPboxADMMsolver.cpp.
 // Built with -ffp-contract=off: the reference is compiled without FMA (plain g++ -O3 on x86-64).
@@ -20,7 +24,22 @@
 
 #include <float.h>
 
+#include <utility>
+
 namespace {
+
+// Diagnostic build only (-DLPBOX_STAMPS, liblpbox_hip_stamps.so): per-phase cycle shares of wave 0, written to
+// bd.stamps[inst*16 + phase].  The shipped library contains no stamp.
+#ifdef LPBOX_STAMPS
+#define STAMP_DECL unsigned long long st_acc[16] = {0}; unsigned long long st_t = __builtin_amdgcn_s_memtime();
+#define STAMP(k) { __builtin_amdgcn_sched_barrier(0); unsigned long long st_n = __builtin_amdgcn_s_memtime(); \
+                   __builtin_amdgcn_s_waitcnt(0xC07F); st_acc[k] += st_n - st_t; st_t = st_n; __builtin_amdgcn_sched_barrier(0); }
+#define STAMP_STORE if (tid == 0 && bd.stamps) { for (int k = 0; k < 16; k++) bd.stamps[(size_t)inst * 16 + k] = st_acc[k]; }
+#else
+#define STAMP_DECL
+#define STAMP(k)
+#define STAMP_STORE
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // wave / block reductions
@@ -62,29 +81,43 @@ __device__ __forceinline__ double wave_allreduce_sum(double v) {
 #endif
 }
 
+__device__ __forceinline__ int wave_max_int(int v) {
+    for (int off = 1; off < 64; off <<= 1) { int o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
 constexpr int RED_MAXV = 5;    // values reduced together
 constexpr int RED_MAXW = 16;   // waves per workgroup
 
-// Sum NV per-thread partials over the workgroup; every thread receives the totals.  `red` is a ping-pong LDS
-// scratch (2 * RED_MAXV * RED_MAXW doubles): a thread can run at most one block_sum ahead of the slowest one.
+// Sum NV per-thread partials over the workgroup; every thread receives the totals.  Wave partials go through LDS and
+// are combined by a second butterfly (lane i reads partial i mod W; balanced tree over the wave index), i.e. ONE LDS
+// round trip instead of W dependent reads.  `red` is a ping-pong scratch (2 * RED_MAXV * RED_MAXW doubles): a thread
+// can run at most one block_sum ahead of the slowest one.
 template <int T, int NV>
 __device__ __forceinline__ void block_sum(double (&v)[NV], double *red, int &parity) {
     constexpr int W = T / 64;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    double *buf = red + parity * (RED_MAXV * RED_MAXW);
+    static_assert(W == 1 || W == 2 || W == 4 || W == 8 || W == 16, "waves per workgroup");
 #pragma unroll
     for (int k = 0; k < NV; k++) v[k] = wave_allreduce_sum(v[k]);
+    if constexpr (W == 1) return;        // one wavefront per instance: no LDS round trip, no barrier
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double *buf = red + parity * (RED_MAXV * RED_MAXW);
     if (lane == 0) {
 #pragma unroll
         for (int k = 0; k < NV; k++) buf[k * RED_MAXW + w] = v[k];
     }
     __syncthreads();
+    double t[NV];
+#pragma unroll
+    for (int k = 0; k < NV; k++) t[k] = buf[k * RED_MAXW + (lane & (W - 1))];
 #pragma unroll
     for (int k = 0; k < NV; k++) {
-        double t = buf[k * RED_MAXW];
-#pragma unroll
-        for (int w2 = 1; w2 < W; w2++) t = t + buf[k * RED_MAXW + w2];
-        v[k] = t;
+        double u = t[k];
+        u = u + dpp_mov<0xB1>(u);                    // waves (0,1) (2,3) ...
+        if (W >= 4) u = u + dpp_mov<0x4E>(u);        // quads of waves
+        if (W >= 8) u = u + dpp_mov<0x141>(u);       // 8 waves
+        if (W >= 16) u = u + dpp_mov<0x140>(u);      // 16 waves
+        v[k] = u;
     }
     parity ^= 1;
 }
@@ -93,65 +126,198 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double *red, int &par
 // LDS carve-up shared by the launcher (size) and the kernel (pointers)
 // ------------------------------------------------------------------------------------------------
 struct LdsLayout {
-    size_t gx, gl0, gl1, gl2, red, csr_ptr, csc_ptr, csr_col, csc_row, total;
+    size_t gx, gl, red, rs_ptr, cs_ptr, rs_col, cs_row, total;
     __host__ __device__ LdsLayout(int NS, int LS, int ZS) {
         size_t o = 0;
         auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 15) & ~size_t(15); return at; };
-        gx = take(sizeof(double) * (size_t)NS);
-        gl0 = take(sizeof(double) * (size_t)LS);
-        gl1 = take(sizeof(double) * (size_t)LS);
-        gl2 = take(sizeof(double) * (size_t)LS);
+        gx = take(sizeof(double) * ((size_t)NS + 1));     // + zero slot at [NS]
+        gl = take(sizeof(double) * 3 * ((size_t)LS + 1)); // three l-vectors interleaved: gl[3*i + c]; zero slot at i = LS
         red = take(sizeof(double) * 2 * RED_MAXV * RED_MAXW);
-        csr_ptr = take(sizeof(int) * ((size_t)LS + 1));
-        csc_ptr = take(sizeof(int) * ((size_t)NS + 1));
-        csr_col = take(sizeof(uint16_t) * (size_t)ZS);
-        csc_row = take(sizeof(uint16_t) * (size_t)ZS);
+        rs_ptr = take(sizeof(int) * ((size_t)NS + 1));
+        cs_ptr = take(sizeof(int) * ((size_t)NS + 1));
+        rs_col = take(sizeof(uint16_t) * (size_t)ZS);
+        cs_row = take(sizeof(uint16_t) * (size_t)ZS);
         total = o;
     }
 };
 
-// y = E*v restricted to this thread's rows: res_i = sum_j E_ij * v_j with j ascending (Eigen CSC product order,
-// LPcpp:102-108), all stored values are 1.0 so the product term is v_j itself.
-template <int T, int EPT>
-__device__ __forceinline__ void rows_gather(const int *s_ptr, const uint16_t *s_col, const double *gx, int l,
-                                            double (&out)[EPT]) {
+// ------------------------------------------------------------------------------------------------
+// gather lists: CAP absolute LDS addresses in registers (+ an LDS index tail for longer lists)
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) double lds_double;
+
+__device__ __forceinline__ unsigned lds_addr(const void *p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p;
+}
+// component COMP (an immediate ds_read offset) of the element at LDS address a
+template <int COMP>
+__device__ __forceinline__ double lds_ld(unsigned a) {
+    return ((const lds_double *)(size_t)a)[COMP];
+}
+
+// per-slot register capacities of the gather lists of one thread (slot s keeps its first at(s) entries in registers)
+template <int... V>
+struct Caps {
+    static constexpr int N = sizeof...(V);
+    static constexpr int total = (V + ... + 0);
+    static constexpr int at(int i) { constexpr int a[N] = {V...}; return a[i]; }
+    static constexpr int off(int i) { constexpr int a[N] = {V...}; int o = 0; for (int k = 0; k < i; k++) o += a[k]; return o; }
+};
+
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+template <typename C>
+struct Lists {
+    unsigned addr[C::total > 0 ? C::total : 1];   // LDS address of each gathered element, padded with the zero slot's address
+    int tail_begin[C::N], tail_end[C::N];         // entries beyond the register capacity: indices read from LDS
+    int wlen[C::N];                               // wave-uniform number of register entries to walk
+    unsigned base, zero;                          // address of element 0 / of the zero slot
+};
+
+// STRIDE = bytes between consecutive elements of the gathered vector (8 for gx, 24 for the interleaved gl)
+template <typename C, int S, int STRIDE>
+__device__ __forceinline__ void build_list(Lists<C> &g, int begin, int end, const uint16_t *idx) {
+    constexpr int CAP = C::at(S), OFF = C::off(S);
 #pragma unroll
-    for (int s = 0; s < EPT; s++) {
-        const int i = s * T + (int)threadIdx.x;
-        double acc = 0.0;
-        if (i < l) {
-            const int k1 = s_ptr[i + 1];
-            for (int k = s_ptr[i]; k < k1; k++) acc += gx[s_col[k]];
+    for (int k = 0; k < CAP; k++) g.addr[OFF + k] = (begin + k < end) ? g.base + STRIDE * (unsigned)idx[begin + k] : g.zero;
+    g.tail_begin[S] = begin + CAP < end ? begin + CAP : end;
+    g.tail_end[S] = end;
+    const int len = end - begin;
+    g.wlen[S] = wave_max_int(len < CAP ? len : CAP);
+}
+
+constexpr int GCH = 4;   // gathers of one slot issued together before their (ordered) additions
+
+template <typename C>
+constexpr int caps_max() { int m = 0; for (int i = 0; i < C::N; i++) m = C::at(i) > m ? C::at(i) : m; return m; }
+
+// out[s] = sum_k src[list_s[k]] (k ascending) for every slot s of the thread, through OP(acc, v) which keeps the exact
+// expression of the reference: `acc + v` for E (stored values 1.0) or `acc + s * v` for the scaled transpose.
+// Chunk-major: round c issues the c-th GCH gathers of EVERY slot before any addition, so EPT*GCH independent LDS reads are
+// in flight (the slots are independent sums; inside a slot the additions stay in ascending order).
+template <typename C, int STRIDE, int COMP, typename OP>
+__device__ __forceinline__ void gather_all(const Lists<C> &g, const uint16_t *idx, OP op, double (&out)[C::N]) {
+    constexpr int N = C::N, MAXCAP = caps_max<C>();
+    double acc[N];
+#pragma unroll
+    for (int s = 0; s < N; s++) acc[s] = 0.0;
+    static_for<MAXCAP / GCH>([&](auto CI) {
+        constexpr int c = decltype(CI)::value * GCH;
+        double v[N][GCH];
+        static_for<N>([&](auto S) {
+            constexpr int s = decltype(S)::value;
+            if constexpr (c < C::at(s)) {
+                if (c < g.wlen[s]) {                                    // wave-uniform
+#pragma unroll
+                    for (int q = 0; q < GCH; q++) v[s][q] = lds_ld<COMP>(g.addr[C::off(s) + c + q]);
+                }
+            }
+        });
+        static_for<N>([&](auto S) {
+            constexpr int s = decltype(S)::value;
+            if constexpr (c < C::at(s)) {
+                if (c < g.wlen[s]) {
+#pragma unroll
+                    for (int q = 0; q < GCH; q++) acc[s] = op(acc[s], v[s][q]);
+                }
+            }
+        });
+    });
+    static_for<N>([&](auto S) {                                         // long lists: indices from LDS
+        constexpr int s = decltype(S)::value;
+        for (int k = g.tail_begin[s]; k < g.tail_end[s]; k += GCH) {
+            unsigned o[GCH];
+#pragma unroll
+            for (int q = 0; q < GCH; q++) o[q] = (k + q < g.tail_end[s]) ? g.base + STRIDE * (unsigned)idx[k + q] : g.zero;
+            double v[GCH];
+#pragma unroll
+            for (int q = 0; q < GCH; q++) v[q] = lds_ld<COMP>(o[q]);
+#pragma unroll
+            for (int q = 0; q < GCH; q++) acc[s] = op(acc[s], v[q]);
         }
-        out[s] = acc;
-    }
+        out[s] = acc[s];
+    });
+}
+
+// two sums per slot from components CA and CB of the gathered elements (rhs assembly)
+template <typename C, int STRIDE, int CA, int CB, typename OPA, typename OPB>
+__device__ __forceinline__ void gather_all2(const Lists<C> &g, const uint16_t *idx, OPA opa, OPB opb, double (&outA)[C::N],
+                                            double (&outB)[C::N]) {
+    constexpr int N = C::N, MAXCAP = caps_max<C>();
+    double a[N], b[N];
+#pragma unroll
+    for (int s = 0; s < N; s++) { a[s] = 0.0; b[s] = 0.0; }
+    static_for<MAXCAP / GCH>([&](auto CI) {
+        constexpr int c = decltype(CI)::value * GCH;
+        double va[N][GCH], vb[N][GCH];
+        static_for<N>([&](auto S) {
+            constexpr int s = decltype(S)::value;
+            if constexpr (c < C::at(s)) {
+                if (c < g.wlen[s]) {
+#pragma unroll
+                    for (int q = 0; q < GCH; q++) {
+                        va[s][q] = lds_ld<CA>(g.addr[C::off(s) + c + q]);
+                        vb[s][q] = lds_ld<CB>(g.addr[C::off(s) + c + q]);
+                    }
+                }
+            }
+        });
+        static_for<N>([&](auto S) {
+            constexpr int s = decltype(S)::value;
+            if constexpr (c < C::at(s)) {
+                if (c < g.wlen[s]) {
+#pragma unroll
+                    for (int q = 0; q < GCH; q++) { a[s] = opa(a[s], va[s][q]); b[s] = opb(b[s], vb[s][q]); }
+                }
+            }
+        });
+    });
+    static_for<N>([&](auto S) {
+        constexpr int s = decltype(S)::value;
+        for (int k = g.tail_begin[s]; k < g.tail_end[s]; k += GCH) {
+            unsigned o[GCH];
+#pragma unroll
+            for (int q = 0; q < GCH; q++) o[q] = (k + q < g.tail_end[s]) ? g.base + STRIDE * (unsigned)idx[k + q] : g.zero;
+            double va[GCH], vb[GCH];
+#pragma unroll
+            for (int q = 0; q < GCH; q++) { va[q] = lds_ld<CA>(o[q]); vb[q] = lds_ld<CB>(o[q]); }
+#pragma unroll
+            for (int q = 0; q < GCH; q++) { a[s] = opa(a[s], va[q]); b[s] = opb(b[s], vb[q]); }
+        }
+        outA[s] = a[s]; outB[s] = b[s];
+    });
 }
 
 // ------------------------------------------------------------------------------------------------
 // ADMM_lp_iters_init (LPcpp:489-763) for every instance: x=1, z=0, rho=25, ...
 // ------------------------------------------------------------------------------------------------
 template <int T, int EPT>
-__global__ void __launch_bounds__(T) lp_init_kernel(LpBatchDev bd, const double *f_org, const double *c1_init) {
+__global__ void __launch_bounds__(T) lp_init_kernel(LpBatchDev bd, const double *f_org, const double *c1_init,
+                                                    const uint8_t *live_init) {
     __shared__ double red[2 * RED_MAXV * RED_MAXW];
     const int inst = blockIdx.x, tid = threadIdx.x;
     int *isc = bd.isc + (size_t)inst * NI_COUNT;
     double *dsc = bd.dsc + (size_t)inst * ND_COUNT;
-    const int n = isc[NI_N], l = isc[NI_L];
+    const int l = isc[NI_L];
     const size_t on = (size_t)inst * bd.NS, ol = (size_t)inst * bd.LS;
     int parity = 0;
     double part[1] = {0.0};
 #pragma unroll
     for (int s = 0; s < EPT; s++) {
         const int pos = s * T + tid;
-        double prod = 0.0;
-        if (pos < n) {
-            bd.x[on + pos] = 1.0;                    // :583-586
-            bd.z1[on + pos] = 0.0; bd.z2[on + pos] = 0.0;   // :616-617
-            bd.pd[on + pos] = 0.0;
-            bd.live[on + pos] = 1;
-            prod = bd.b[on + pos] * 1.0;             // best_bin_obj = b.dot(x0), :727
-        }
-        part[0] = part[0] + prod;
+        const bool isvar = live_init[on + pos] != 0;   // storage positions without a variable ("holes") behave like fixed zeros
+        bd.x[on + pos] = isvar ? 1.0 : 0.0;            // :583-586
+        bd.z1[on + pos] = 0.0; bd.z2[on + pos] = 0.0;  // :616-617
+        bd.pd[on + pos] = 0.0;
+        bd.live[on + pos] = isvar ? 1 : 0;
+        part[0] = part[0] + (isvar ? bd.b[on + pos] * 1.0 : 0.0);   // best_bin_obj = b.dot(x0), :727
     }
     for (int i = tid; i < l; i += T) { bd.z4[ol + i] = 0.0; bd.f[ol + i] = f_org[ol + i]; }   // :650
     block_sum<T, 1>(part, red, parity);
@@ -167,7 +333,7 @@ __global__ void __launch_bounds__(T) lp_init_kernel(LpBatchDev bd, const double 
         dsc[ND_C1] = c1_init[inst];                  // pow(n, 1/p), p = 2 (:427,:503)
         dsc[ND_CVG1] = 0.0; dsc[ND_CVG2] = 0.0; dsc[ND_OBJ_VAL] = 0.0;
         dsc[ND_PREV_SUM] = 0.0; dsc[ND_PREV_OBJ] = 0.0;
-        isc[NI_NLIVE] = n;
+        isc[NI_NLIVE] = isc[NI_N];
         isc[NI_RHO_UPDATED] = 1;                     // LPh:214
         isc[NI_ITER] = 0; isc[NI_HIST_N] = 0; isc[NI_RET] = 0; isc[NI_STOP] = 0;
         isc[NI_PCG_TOTAL] = 0; isc[NI_OUTER_TOTAL] = 0; isc[NI_LAST_PCG] = 0; isc[NI_PLAIN_ITER_P1] = 0;
@@ -179,8 +345,10 @@ __global__ void __launch_bounds__(T) lp_init_kernel(LpBatchDev bd, const double 
 // ------------------------------------------------------------------------------------------------
 // The ADMM window: iterations [iter_start, iter_end) of ADMM_lp_iters (LPcpp:766-1095, l2f == 0) or
 // ADMM_lp_iters_l2f (LPcpp:1098-1574, l2f == 1) for one instance per workgroup.
+//   T    threads per instance, EPT variable (and row) slots per thread,
+//   RCAPS / CCAPS  per-slot register capacities (Caps<...>) of the row-task / column gather lists.
 // ------------------------------------------------------------------------------------------------
-template <int T, int EPT>
+template <int T, int EPT, typename RCAPS, typename CCAPS>
 __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_start, int iter_end, int l2f) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int inst = blockIdx.x, tid = threadIdx.x;
@@ -188,49 +356,50 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
     double *dsc = bd.dsc + (size_t)inst * ND_COUNT;
     if (!isc[NI_ACTIVE]) return;
 
-    const int n = isc[NI_N], l = isc[NI_L], nnz = isc[NI_NNZ];
+    const int nnz = isc[NI_NNZ];
     const size_t on = (size_t)inst * bd.NS, ol = (size_t)inst * bd.LS, oz = (size_t)inst * bd.ZS;
 
     const LdsLayout L(bd.NS, bd.LS, bd.ZS);
     double *gx = (double *)(smem + L.gx);
-    double *gl0 = (double *)(smem + L.gl0);
-    double *gl1 = (double *)(smem + L.gl1);
-    double *gl2 = (double *)(smem + L.gl2);
+    double *gl = (double *)(smem + L.gl);       // gl[3*i + c]: c = 0: q = E*p / f - y3, 1: z4, 2: E*y1
     double *red = (double *)(smem + L.red);
-    int *s_csr_ptr = (int *)(smem + L.csr_ptr);
-    int *s_csc_ptr = (int *)(smem + L.csc_ptr);
-    uint16_t *s_csr_col = (uint16_t *)(smem + L.csr_col);
-    uint16_t *s_csc_row = (uint16_t *)(smem + L.csc_row);
+    int *s_rs_ptr = (int *)(smem + L.rs_ptr);
+    int *s_cs_ptr = (int *)(smem + L.cs_ptr);
+    uint16_t *s_rs_col = (uint16_t *)(smem + L.rs_col);
+    uint16_t *s_cs_row = (uint16_t *)(smem + L.cs_row);
 
     // ---- stage the index sets of E into LDS ----
     {
-        const int *gp = bd.csr_ptr + (size_t)inst * (bd.LS + 1);
-        for (int i = tid; i <= l; i += T) s_csr_ptr[i] = gp[i];
-        const int *gc = bd.csc_ptr + (size_t)inst * (bd.NS + 1);
-        for (int i = tid; i <= n; i += T) s_csc_ptr[i] = gc[i];
-        const uint16_t *c0 = bd.csr_col + oz, *r0 = bd.csc_row + oz;
-        for (int k = tid; k < nnz; k += T) { s_csr_col[k] = c0[k]; s_csc_row[k] = r0[k]; }
+        const int *gp = bd.rs_ptr + (size_t)inst * (bd.NS + 1);
+        const int *gc = bd.cs_ptr + (size_t)inst * (bd.NS + 1);
+        for (int i = tid; i <= bd.NS; i += T) { s_rs_ptr[i] = gp[i]; s_cs_ptr[i] = gc[i]; }
+        const uint16_t *c0 = bd.rs_col + oz, *r0 = bd.cs_row + oz;
+        for (int k = tid; k < nnz; k += T) { s_rs_col[k] = c0[k]; s_cs_row[k] = r0[k]; }
+        if (tid == 0) { gx[bd.NS] = 0.0; gl[3 * bd.LS] = 0.0; gl[3 * bd.LS + 1] = 0.0; gl[3 * bd.LS + 2] = 0.0; }   // zero slots
     }
 
     // ---- per-thread state ----
     double x[EPT], z1[EPT], z2[EPT], b[EPT], pd[EPT], dinv[EPT], Esq[EPT];
     bool live[EPT], valid[EPT];
     double z4[EPT], f[EPT], Ex[EPT], y3[EPT];
-    bool rvalid[EPT];
+    bool rvalid[EPT];       // this lane is the LEADER (lane 0) of a row task: it owns the row's l-vector entries
+    bool rtask[EPT];        // this lane takes part in a row sum
+    int rrow[EPT];          // original row id of the row task in slot s
+    int rG[EPT];            // lanes sharing that row (1,2,4,8)
 #pragma unroll
     for (int s = 0; s < EPT; s++) {
         const int pos = s * T + tid;
-        valid[s] = pos < n;
-        x[s] = z1[s] = z2[s] = b[s] = pd[s] = 0.0;
-        live[s] = false;
-        if (valid[s]) {
-            x[s] = bd.x[on + pos]; z1[s] = bd.z1[on + pos]; z2[s] = bd.z2[on + pos];
-            b[s] = bd.b[on + pos]; pd[s] = bd.pd[on + pos];
-            live[s] = bd.live[on + pos] != 0;
-        }
-        rvalid[s] = pos < l;
+        valid[s] = true;    // every storage position exists; positions without a variable are never live
+        x[s] = bd.x[on + pos]; z1[s] = bd.z1[on + pos]; z2[s] = bd.z2[on + pos];
+        b[s] = bd.b[on + pos]; pd[s] = bd.pd[on + pos];
+        live[s] = bd.live[on + pos] != 0;
+        const int rid = bd.rid[on + pos], meta = bd.rmeta[on + pos];
+        rtask[s] = rid != 0xFFFF;
+        rvalid[s] = rtask[s] && (meta & 15) == 0;
+        rrow[s] = rtask[s] ? rid : 0;
+        rG[s] = rtask[s] ? (meta >> 4) : 1;
         z4[s] = f[s] = 0.0;
-        if (rvalid[s]) { z4[s] = bd.z4[ol + pos]; f[s] = bd.f[ol + pos]; }
+        if (rvalid[s]) { z4[s] = bd.z4[ol + rrow[s]]; f[s] = bd.f[ol + rrow[s]]; }
         Ex[s] = y3[s] = 0.0;
     }
     double rho1 = dsc[ND_RHO1], rho2 = dsc[ND_RHO2], rho4 = dsc[ND_RHO4];
@@ -250,12 +419,39 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
     int ret = 0, stop = LP_STOP_NONE, parity = 0;
 
     __syncthreads();   // index sets staged
-#pragma unroll
-    for (int s = 0; s < EPT; s++) {   // Esq_diag_j = sum of squared entries of column j (LPcpp:2378-2390); entries are 1.0
-        double e = 0.0;
-        if (valid[s]) { const int pos = s * T + tid; e = (double)(s_csc_ptr[pos + 1] - s_csc_ptr[pos]); }   // = 1.0*1.0 added c times
-        Esq[s] = e;
-    }
+
+    // ---- gather lists of this thread's rows and columns, kept in registers for the whole launch ----
+    static_assert(RCAPS::N == EPT && CCAPS::N == EPT, "one capacity per slot");
+    Lists<RCAPS> rl;
+    Lists<CCAPS> cl;
+    rl.base = lds_addr(gx); rl.zero = lds_addr(gx + bd.NS);
+    cl.base = lds_addr(gl); cl.zero = lds_addr(gl + 3 * bd.LS);
+    int rGmax[EPT];              // wave-uniform largest lane group in the slot
+    static_for<EPT>([&](auto S) {
+        constexpr int s = decltype(S)::value;
+        const int pos = s * T + tid;
+        build_list<RCAPS, s, 8>(rl, s_rs_ptr[pos], s_rs_ptr[pos + 1], s_rs_col);
+        rGmax[s] = wave_max_int(rG[s]);
+        const int cb = s_cs_ptr[pos], ce = s_cs_ptr[pos + 1];
+        build_list<CCAPS, s, 24>(cl, cb, ce, s_cs_row);
+        Esq[s] = (double)(ce - cb);   // Esq_diag_j = sum of squared entries of column j (LPcpp:2378-2390); entries are 1.0
+    });
+    auto op_add = [](double acc, double v) { return acc + v; };                 // res += 1.0 * v
+    // out = (E * gx)_row for this thread's row tasks: the G lanes of a task add their interleaved share of the row in
+    // ascending column order, then combine by an xor butterfly inside the (aligned) lane group; every lane of the group
+    // ends up with the row sum, the leader uses it.
+    auto rows_gather = [&](double (&out)[EPT]) {
+        double part[EPT];
+        gather_all<RCAPS, 8, 0>(rl, s_rs_col, op_add, part);
+        static_for<EPT>([&](auto S) {
+            constexpr int s = decltype(S)::value;
+            double v = part[s];
+            if (rGmax[s] >= 2) { const double u = v + dpp_mov<0xB1>(v); v = rG[s] >= 2 ? u : v; }
+            if (rGmax[s] >= 4) { const double u = v + dpp_mov<0x4E>(v); v = rG[s] >= 4 ? u : v; }
+            if (rGmax[s] >= 8) { const double u = v + dpp_mov<0x141>(v); v = rG[s] >= 8 ? u : v; }
+            out[s] = v;
+        });
+    };
 
     // ---- early fixing: apply this call's fix vector (LPcpp:1124-1335) as a mask ----
     bool finished = false;
@@ -266,10 +462,10 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
 #pragma unroll
         for (int s = 0; s < EPT; s++) {
             const int pos = s * T + tid;
-            nf[s] = valid[s] ? bd.newfix[on + pos] : 0;
+            nf[s] = bd.newfix[on + pos];
             const double val = nf[s] == 2 ? 1.0 : 0.0;
             part[0] = part[0] + (nf[s] ? b[s] * val : 0.0);     // fix_obj = b2.dot(x2), :1237
-            if (valid[s]) gx[pos] = nf[s] ? val : 0.0;
+            gx[pos] = nf[s] ? val : 0.0;
         }
         block_sum<T, 1>(part, red, parity);                      // (barrier inside also publishes gx)
         fix_obj = part[0];
@@ -279,7 +475,7 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
             for (int s = 0; s < EPT; s++) if (nf[s]) { live[s] = false; x[s] = nf[s] == 2 ? 1.0 : 0.0; }
         } else {
             double cnt[EPT];
-            rows_gather<T, EPT>(s_csr_ptr, s_csr_col, gx, l, cnt);   // E2*x2, :1276
+            rows_gather(cnt);                                         // E2*x2, :1276
 #pragma unroll
             for (int s = 0; s < EPT; s++) {
                 f[s] = f[s] - cnt[s];                                 // f1 = f - E2*x2, :1278
@@ -313,10 +509,12 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
 #pragma unroll
         for (int s = 0; s < EPT; s++) if (valid[s]) gx[s * T + tid] = live[s] ? x[s] : 0.0;
         __syncthreads();
-        rows_gather<T, EPT>(s_csr_ptr, s_csr_col, gx, l, Ex);
+        rows_gather(Ex);
 
         int cc = 0;
+        STAMP_DECL
         for (; it < iter_end; ++it) {
+            STAMP(15)
             // ---------------- y1 (box) and y2 (shifted L2 sphere), LPcpp:806-818 ----------------
             double y1[EPT], y2[EPT];
             double pn[1] = {0.0};
@@ -334,12 +532,13 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
 #pragma unroll
                 for (int s = 0; s < EPT; s++) y2[s] = y2[s] * c1 / c2 + 0.5;
             }
+            STAMP(0)
             // ---------------- y3 = max(0, f - E x - z4/rho4), LPcpp:824-828 ----------------
 #pragma unroll
             for (int s = 0; s < EPT; s++) {
                 const double v = f[s] - Ex[s] - z4[s] / rho4;
                 y3[s] = v < 0 ? 0 : v;
-                if (rvalid[s]) { gl0[s * T + tid] = f[s] - y3[s]; gl1[s * T + tid] = z4[s]; }
+                if (rvalid[s]) { gl[3 * rrow[s]] = f[s] - y3[s]; gl[3 * rrow[s] + 1] = z4[s]; }
                 if (valid[s]) gx[s * T + tid] = live[s] ? y1[s] : 0.0;      // PCG start x0 = y1 (:892)
             }
             __syncthreads();
@@ -359,20 +558,14 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
                 for (int s = 0; s < EPT; s++) { pd[s] += inc; pd[s] += inc4 * Esq[s]; }
                 r4Et = learning_fact * r4Et;                          // rho4_E_transpose *= learning_fact (:864)
             }
+            const double r4 = r4Et;
+            auto op_scaled = [r4](double acc, double v) { return acc + r4 * v; };   // res += (rho4*1.0) * v
             // ---------------- rhs (:872-878) and q = E*y1 ----------------
-            double rhs[EPT];
+            double rhs[EPT], tAs[EPT], tBs[EPT];
+            gather_all2<CCAPS, 24, 0, 1>(cl, s_cs_row, op_scaled, op_add, tAs, tBs);   // (rho4 E^T)(f - y3) and E^T z4 in one pass
 #pragma unroll
             for (int s = 0; s < EPT; s++) {
-                double tA = 0.0, tB = 0.0;
-                if (valid[s]) {
-                    const int pos = s * T + tid;
-                    const int k1 = s_csc_ptr[pos + 1];
-                    for (int k = s_csc_ptr[pos]; k < k1; k++) {
-                        const int i = s_csc_row[k];
-                        tA += r4Et * gl0[i];                          // (rho4 E^T)(f - y3)
-                        tB += gl1[i];                                 // E^T z4
-                    }
-                }
+                const double tA = tAs[s], tB = tBs[s];
                 double r_ = (rho1 * y1[s] + rho2 * y2[s]) - ((b[s] + z1[s]) + z2[s]);
                 r_ += tA;
                 r_ -= tB;
@@ -380,9 +573,9 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
             }
             {
                 double q[EPT];
-                rows_gather<T, EPT>(s_csr_ptr, s_csr_col, gx, l, q);
+                rows_gather(q);
 #pragma unroll
-                for (int s = 0; s < EPT; s++) if (rvalid[s]) gl2[s * T + tid] = q[s];
+                for (int s = 0; s < EPT; s++) if (rvalid[s]) gl[3 * rrow[s] + 2] = q[s];
             }
             __syncthreads();
             if (rhoUpdated) {                                         // DiagonalPreconditioner::compute (:883-890)
@@ -390,17 +583,15 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
                 for (int s = 0; s < EPT; s++) dinv[s] = (pd[s] != 0.0) ? 1.0 / pd[s] : 1.0;
                 rhoUpdated = 0;
             }
+            STAMP(1)
             // ---------------- PCG (LPcpp:251-335) on (dI*I + rho4 E^T E) x = rhs ----------------
             double xt[EPT], r[EPT], p[EPT];
             double p3[3] = {0.0, 0.0, 0.0};
+            double tcol[EPT];
+            gather_all<CCAPS, 24, 2>(cl, s_cs_row, op_scaled, tcol);
 #pragma unroll
             for (int s = 0; s < EPT; s++) {
-                double t = 0.0;
-                if (valid[s]) {
-                    const int pos = s * T + tid;
-                    const int k1 = s_csc_ptr[pos + 1];
-                    for (int k = s_csc_ptr[pos]; k < k1; k++) t += r4Et * gl2[s_csc_row[k]];
-                }
+                const double t = tcol[s];
                 xt[s] = y1[s];
                 double Mx = 0.0;
                 Mx += dI * (1.0 * xt[s]);
@@ -412,6 +603,7 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
                 p3[2] = p3[2] + (live[s] ? r[s] * p[s] : 0.0);        // absNew :294
             }
             block_sum<T, 3>(p3, red, parity);
+            STAMP(2)
             const double rhsNorm2 = p3[0];
             double residualNorm2 = p3[1], absNew = p3[2];
             int k_it = 0;
@@ -427,30 +619,31 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
 #pragma unroll
                         for (int s = 0; s < EPT; s++) if (valid[s]) gx[s * T + tid] = live[s] ? p[s] : 0.0;
                         __syncthreads();
+                        STAMP(3)
                         {
                             double q[EPT];
-                            rows_gather<T, EPT>(s_csr_ptr, s_csr_col, gx, l, q);
+                            rows_gather(q);
+                            STAMP(4)
 #pragma unroll
-                            for (int s = 0; s < EPT; s++) if (rvalid[s]) gl0[s * T + tid] = q[s];
+                            for (int s = 0; s < EPT; s++) if (rvalid[s]) gl[3 * rrow[s]] = q[s];
                         }
                         __syncthreads();
+                        STAMP(5)
                         double tmp[EPT];
                         double p1[1] = {0.0};
+                        gather_all<CCAPS, 24, 0>(cl, s_cs_row, op_scaled, tcol);
 #pragma unroll
                         for (int s = 0; s < EPT; s++) {               // tmp = M p (:298), fused p.tmp
-                            double t = 0.0;
-                            if (valid[s]) {
-                                const int pos = s * T + tid;
-                                const int k1 = s_csc_ptr[pos + 1];
-                                for (int k = s_csc_ptr[pos]; k < k1; k++) t += r4Et * gl0[s_csc_row[k]];
-                            }
+                            const double t = tcol[s];
                             double Mp = 0.0;
                             Mp += dI * (1.0 * p[s]);
                             Mp += t;
                             tmp[s] = Mp;
                             p1[0] = p1[0] + (live[s] ? p[s] * tmp[s] : 0.0);
                         }
+                        STAMP(6)
                         block_sum<T, 1>(p1, red, parity);
+                        STAMP(7)
                         const double alpha = absNew / p1[0];          // :300
                         if (alpha < 0) { pcg_fail = true; break; }    // :301
                         double p2[2] = {0.0, 0.0};
@@ -463,7 +656,9 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
                             p2[0] = p2[0] + (live[s] ? r[s] * r[s] : 0.0);   // :305
                             p2[1] = p2[1] + (live[s] ? r[s] * z[s] : 0.0);   // :317
                         }
+                        STAMP(8)
                         block_sum<T, 2>(p2, red, parity);
+                        STAMP(9)
                         residualNorm2 = p2[0];
                         if (residualNorm2 < threshold) { k_it++; break; }     // :309-312
                         const double absOld = absNew;
@@ -472,9 +667,11 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
 #pragma unroll
                         for (int s = 0; s < EPT; s++) p[s] = z[s] + beta * p[s];   // :319
                         k_it++;
+                        STAMP(10)
                     }
                 }
             }
+            STAMP(11)
             last_pcg = k_it;
             pcg_total += k_it;
             if (pcg_fail) stop = LP_STOP_PCG;
@@ -498,7 +695,7 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
                 if (valid[s]) gx[s * T + tid] = live[s] ? x[s] : 0.0;
             }
             __syncthreads();
-            rows_gather<T, EPT>(s_csr_ptr, s_csr_col, gx, l, Ex);     // E*x: feeds z4 now and y3 of the next iteration
+            rows_gather(Ex);                                          // E*x: feeds z4 now and y3 of the next iteration
 #pragma unroll
             for (int s = 0; s < EPT; s++) {
                 const double d = g4 * ((Ex[s] + y3[s]) - f[s]);
@@ -516,7 +713,9 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
                 p5[3] = p5[3] + (live[s] ? b[s] * x[s] : 0.0);
                 p5[4] = p5[4] + (live[s] ? b[s] * xb : 0.0);
             }
+            STAMP(12)
             block_sum<T, 5>(p5, red, parity);
+            STAMP(13)
             {
                 const double xn = sqrt(p5[0]);
                 const double temp0 = (xn < 2.2204e-16) ? 2.2204e-16 : xn;
@@ -564,7 +763,9 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
             if (std_obj <= LP_STD_THRESHOLD) { ret = 1; stop = LP_STOP_OBJSTD; break; }   // :977
             cur_obj = p5[4];                                          // :1001-1003
             if (best_bin_obj >= cur_obj) best_bin_obj = cur_obj;
+            STAMP(14)
         }
+        STAMP_STORE
     }
 
     // ---- write the state back ----
@@ -575,7 +776,7 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
             bd.x[on + pos] = x[s]; bd.z1[on + pos] = z1[s]; bd.z2[on + pos] = z2[s]; bd.pd[on + pos] = pd[s];
             bd.live[on + pos] = live[s] ? 1 : 0;
         }
-        if (rvalid[s]) { bd.z4[ol + pos] = z4[s]; bd.f[ol + pos] = f[s]; }
+        if (rvalid[s]) { bd.z4[ol + rrow[s]] = z4[s]; bd.f[ol + rrow[s]] = f[s]; }
     }
     if (tid == 0) {
         dsc[ND_RHO1] = rho1; dsc[ND_RHO2] = rho2; dsc[ND_RHO4] = rho4;
@@ -596,14 +797,15 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
     }
 }
 
-// x_iters export (get_x_iters_d, LPcpp:1616-1627): out[inst][r*ws + c] = x after iteration c of live variable r.
-__global__ void lp_pack_xiters_kernel(LpBatchDev bd, const int *left_idx, const int *rows, int ws, double *out,
+// x_iters export (get_x_iters_d, LPcpp:1616-1627): out[inst][r*ws + c] = x after iteration c of live variable r
+// (live_pos[r] = storage position of the r-th live variable in original order).
+__global__ void lp_pack_xiters_kernel(LpBatchDev bd, const int *live_pos, const int *rows, int ws, double *out,
                                       long out_stride) {
     const int inst = blockIdx.y;
     const int nr = rows[inst];
     const long total = (long)nr * ws;
     const double *xh = bd.xhist + (size_t)inst * bd.ws_cap * bd.NS;
-    const int *li = left_idx + (size_t)inst * bd.NS;
+    const int *li = live_pos + (size_t)inst * bd.NS;
     double *o = out + (size_t)inst * out_stride;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const int r = (int)(e / ws), c = (int)(e % ws);
@@ -621,20 +823,21 @@ size_t lp_window_lds_bytes(int T, int NS, int LS, int ZS) {
     return LdsLayout(NS, LS, ZS).total;
 }
 
-#define LP_DISPATCH(KERNEL_CALL)                                                                   \
-    if (T == 256 && EPT == 1) { KERNEL_CALL(256, 1) }                                              \
-    else if (T == 256 && EPT == 2) { KERNEL_CALL(256, 2) }                                         \
-    else if (T == 256 && EPT == 4) { KERNEL_CALL(256, 4) }                                         \
-    else if (T == 512 && EPT == 1) { KERNEL_CALL(512, 1) }                                         \
-    else if (T == 512 && EPT == 2) { KERNEL_CALL(512, 2) }                                         \
-    else if (T == 512 && EPT == 4) { KERNEL_CALL(512, 4) }                                         \
-    else if (T == 1024 && EPT == 1) { KERNEL_CALL(1024, 1) }                                       \
-    else if (T == 1024 && EPT == 2) { KERNEL_CALL(1024, 2) }                                       \
-    else if (T == 1024 && EPT == 4) { KERNEL_CALL(1024, 4) }                                       \
+// (threads, slots per thread) -> per-slot register capacities of the row-task / column gather lists.
+#define LP_DISPATCH(KERNEL_CALL)                                                                                         \
+    if (T == 256 && EPT == 1) { KERNEL_CALL(256, 1, (Caps<12>), (Caps<24>)) }                                       \
+    else if (T == 256 && EPT == 2) { KERNEL_CALL(256, 2, (Caps<12, 12>), (Caps<24, 8>)) }                                \
+    else if (T == 256 && EPT == 4) { KERNEL_CALL(256, 4, (Caps<12, 12, 12, 12>), (Caps<24, 8, 8, 8>)) }                  \
+    else if (T == 256 && EPT == 8) { KERNEL_CALL(256, 8, (Caps<8, 8, 8, 8, 8, 8, 8, 8>), (Caps<8, 8, 8, 8, 4, 4, 4, 4>)) } \
+    else if (T == 512 && EPT == 1) { KERNEL_CALL(512, 1, (Caps<12>), (Caps<24>)) }                                       \
+    else if (T == 512 && EPT == 2) { KERNEL_CALL(512, 2, (Caps<12, 12>), (Caps<16, 8>)) }                                \
     else return hipErrorInvalidConfiguration;
 
-hipError_t lp_launch_init(const LpBatchDev &bd, int T, int EPT, const double *f_org, const double *c1_init, hipStream_t s) {
-#define CALL_INIT(TT, EE) hipLaunchKernelGGL((lp_init_kernel<TT, EE>), dim3(bd.B), dim3(TT), 0, s, bd, f_org, c1_init);
+#define LP_UNPAREN(...) __VA_ARGS__
+
+hipError_t lp_launch_init(const LpBatchDev &bd, int T, int EPT, const double *f_org, const double *c1_init,
+                          const uint8_t *live_init, hipStream_t s) {
+#define CALL_INIT(TT, EE, RR, CCC) hipLaunchKernelGGL((lp_init_kernel<TT, EE>), dim3(bd.B), dim3(TT), 0, s, bd, f_org, c1_init, live_init);
     LP_DISPATCH(CALL_INIT)
 #undef CALL_INIT
     return hipGetLastError();
@@ -642,21 +845,21 @@ hipError_t lp_launch_init(const LpBatchDev &bd, int T, int EPT, const double *f_
 
 hipError_t lp_launch_window(const LpBatchDev &bd, int T, int EPT, size_t lds, int iter_start, int iter_end, int l2f,
                             hipStream_t s) {
-#define CALL_WIN(TT, EE)                                                                                       \
+#define CALL_WIN(TT, EE, RR, CCC)                                                                              \
     {                                                                                                          \
-        hipError_t e = hipFuncSetAttribute((const void *)lp_window_kernel<TT, EE>,                             \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
+        auto kfn = lp_window_kernel<TT, EE, LP_UNPAREN RR, LP_UNPAREN CCC>;                                    \
+        hipError_t e = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return e;                                                                         \
-        hipLaunchKernelGGL((lp_window_kernel<TT, EE>), dim3(bd.B), dim3(TT), lds, s, bd, iter_start, iter_end, l2f); \
+        hipLaunchKernelGGL(kfn, dim3(bd.B), dim3(TT), lds, s, bd, iter_start, iter_end, l2f);                  \
     }
     LP_DISPATCH(CALL_WIN)
 #undef CALL_WIN
     return hipGetLastError();
 }
 
-hipError_t lp_launch_pack_xiters(const LpBatchDev &bd, const int *left_idx, const int *rows, int ws, double *out,
+hipError_t lp_launch_pack_xiters(const LpBatchDev &bd, const int *live_pos, const int *rows, int ws, double *out,
                                  long out_stride, hipStream_t s) {
     dim3 grid(8, bd.B);
-    hipLaunchKernelGGL(lp_pack_xiters_kernel, grid, dim3(256), 0, s, bd, left_idx, rows, ws, out, out_stride);
+    hipLaunchKernelGGL(lp_pack_xiters_kernel, grid, dim3(256), 0, s, bd, live_pos, rows, ws, out, out_stride);
     return hipGetLastError();
 }

@@ -9,7 +9,9 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "liblpbox_hip.so")
+# LPBOX_LIB_VARIANT=stamps selects the diagnostic build with in-kernel phase stamps (make -C csrc stamps)
+_VARIANT = os.environ.get("LPBOX_LIB_VARIANT", "")
+LIB_PATH = os.path.join(HERE, "liblpbox_hip%s.so" % (("_" + _VARIANT) if _VARIANT else ""))
 
 FLAVOUR_LP = 0
 FLAVOUR_SEG = 1
@@ -43,6 +45,8 @@ SYMBOLS = {
     "lpbox_check_infeasible_lpbox": (C.c_int, [C.c_void_p, C.c_int]),
     "lpbox_check_infeasible_l2f": (C.c_int, [C.c_void_p, C.c_int]),
     "lpbox_get_config": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "lpbox_get_layout": (C.c_int, [C.c_void_p, C.c_int, _ip]),
+    "lpbox_get_row_split": (C.c_int, [C.c_void_p, C.c_int, _ip]),
     "lpbox_get_counters": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "lpbox_get_stop": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "lpbox_kernel_time": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]),

@@ -161,6 +161,18 @@ class LpBatch:
         check(self._L.lpbox_get_config(self._h, C.byref(t), C.byref(e), C.byref(l)), "lpbox_get_config")
         return dict(threads=t.value, elems_per_thread=e.value, lds_bytes=l.value)
 
+    def layout(self, idx=0):
+        """Storage position of every variable (the reduction tree of the kernels is defined over positions)."""
+        pos = np.zeros(self.get_org_n(idx), np.int32)
+        check(self._L.lpbox_get_layout(self._h, idx, pos), "lpbox_get_layout")
+        return pos
+
+    def row_split(self, idx=0):
+        """Lanes (1,2,4,8) sharing the sum of each row of E inside the kernels."""
+        g = np.zeros(self.get_l(idx), np.int32)
+        check(self._L.lpbox_get_row_split(self._h, idx, g), "lpbox_get_row_split")
+        return g
+
     def counters(self, idx=0):
         o, p = C.c_longlong(), C.c_longlong()
         check(self._L.lpbox_get_counters(self._h, idx, C.byref(o), C.byref(p)), "lpbox_get_counters")

@@ -91,8 +91,15 @@ int lpbox_check_infeasible_lpbox(lpbox_t *h, int idx);        /* LP pxd:20 (LPcp
 int lpbox_check_infeasible_l2f(lpbox_t *h, int idx);          /* LP pxd:21 (LPcpp:1593-1612): count, >= 0   */
 
 /* ---- extensions beyond the pxd (batching, measurement, inspection) ---------------------------- */
-/* Workgroup geometry picked for the batch: threads per instance (the reduction tree depends on it). */
+/* Workgroup geometry picked for the batch: threads per instance and slots per thread (threads*slots storage positions;
+ * the reduction tree depends on both). */
 int lpbox_get_config(lpbox_t *h, int *threads, int *elems_per_thread, int *lds_bytes);
+/* Storage position of every variable of instance idx (pos_of_var[org_n]): the kernels keep variables sorted by column
+ * length, and the reduction tree is defined over positions (element at position p -> thread p % threads). */
+int lpbox_get_layout(lpbox_t *h, int idx, int *pos_of_var);
+/* Number of lanes (1,2,4,8) that share the sum of each row of E in instance idx (lanes_of_row[l]): lane g adds the entries
+ * g, g+G, ... of the row in ascending column order, the G partial sums are combined by a butterfly. */
+int lpbox_get_row_split(lpbox_t *h, int idx, int *lanes_of_row);
 /* Counters accumulated since init: outer ADMM iterations and PCG iterations of instance idx (LPcpp:894 maxiter). */
 int lpbox_get_counters(lpbox_t *h, int idx, long long *outer_iters, long long *pcg_iters);
 /* Which stop fired in the last call: 0 none, 1 y1_y2, 2 obj_std, 3 PCG alpha<0, 4 all fixed; and iter+1 of the last plain call (LPcpp:1081). */

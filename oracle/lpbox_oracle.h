@@ -40,6 +40,11 @@ void   lpo_destroy(lpo_t *o);
 
 /* Select the reduction order (default LPO_ORDER_EIGEN). T = workgroup threads of the GPU order. */
 void lpo_set_order(lpo_t *o, int mode, int T);
+/* GPU order only: the kernels store variable j at position pos_of_var[j] (lpbox_get_layout) and the reduction tree is
+ * defined over positions.  NULL / never called = identity. */
+void lpo_set_positions(lpo_t *o, const int *pos_of_var, int n, int npos);
+/* GPU order only: lanes_of_row[i] in {1,2,4,8} lanes share the sum of row i of E (lpbox_get_row_split). */
+void lpo_set_row_split(lpo_t *o, const int *lanes_of_row, int l);
 /* 1 = print the reference's stop messages to stdout (default 0 = quiet). */
 void lpo_set_verbose(lpo_t *o, int verbose);
 

@@ -12,8 +12,8 @@ def lp_instances(name):
     return O.load_lp_batch(os.path.join(GOLDEN, name))
 
 
-def make_oracle(I, order=O.ORDER_EIGEN, T=512):
-    s = O.LpOracle(0, order=order, T=T)
+def make_oracle(I, order=O.ORDER_EIGEN, T=512, positions=None, npos=0, row_split=None):
+    s = O.LpOracle(0, order=order, T=T, positions=positions, npos=npos, row_split=row_split)
     s.set_problem(I["n"], I["l"], I["colptr"], I["rowidx"], I["b"], I.get("f"))
     s.solve_init()
     return s
@@ -34,3 +34,14 @@ def bits_equal(a, b):
     a = np.ascontiguousarray(a, np.float64)
     b = np.ascontiguousarray(b, np.float64)
     return a.shape == b.shape and np.array_equal(a.view(np.uint64), b.view(np.uint64))
+
+
+def oracle_like(g, I):
+    """CPU oracle configured with the reduction tree of the HIP solver `g` (threads + storage positions)."""
+    return oracle_for(g.batch if hasattr(g, "batch") else g, 0, I)
+
+
+def oracle_for(batch, idx, I):
+    cfg = batch.config()
+    return make_oracle(I, O.ORDER_GPU, cfg["threads"], batch.layout(idx), cfg["threads"] * cfg["elems_per_thread"],
+                       batch.row_split(idx))

@@ -4,7 +4,7 @@ could not be held over a whole solve)."""
 import numpy as np
 import pytest
 
-from helpers import bits_equal, lp_instances, make_oracle, scripted_fix_vec
+from helpers import bits_equal, lp_instances, oracle_for, oracle_like, scripted_fix_vec
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -37,8 +37,7 @@ def compare_state(g, o, tag=""):
 def test_first_windows_bit_exact(fixture, idx):
     I = lp_instances(fixture)[idx]
     g = gpu_solver(I)
-    T = g.batch.config()["threads"]
-    o = make_oracle(I, O.ORDER_GPU, T)
+    o = oracle_like(g, I)
     vec = np.zeros(I["n"])
     for w in range(3):
         rg = g.solve_iter_l2f(w * 100, (w + 1) * 100, vec, 0)
@@ -61,7 +60,7 @@ def test_first_windows_bit_exact(fixture, idx):
 def test_full_plain_solve_bit_exact(idx):
     I = lp_instances("lp_100_500_seed0.npz")[idx]
     g = gpu_solver(I)
-    o = make_oracle(I, O.ORDER_GPU, g.batch.config()["threads"])
+    o = oracle_like(g, I)
     rg = g.solve_iter(0, 2e4)
     ro = o.solve_iter(0, 20000)
     assert rg == ro
@@ -81,7 +80,7 @@ def test_early_fix_windows_bit_exact():
     """The product loop of LP/trainer.py:504-545 with a scripted policy instead of the trained net."""
     I = lp_instances("lp_100_500_seed0.npz")[4]
     g = gpu_solver(I)
-    o = make_oracle(I, O.ORDER_GPU, g.batch.config()["threads"])
+    o = oracle_like(g, I)
     ws = 100
     vec, num = np.zeros(I["n"]), 0
     fixed_any = False
@@ -112,7 +111,7 @@ def test_n2000_windows_bit_exact():
     g = gpu_solver(I)
     cfg = g.batch.config()
     assert cfg["elems_per_thread"] * cfg["threads"] >= 2000
-    o = make_oracle(I, O.ORDER_GPU, cfg["threads"])
+    o = oracle_like(g, I)
     vec = np.zeros(I["n"])
     for w in range(2):
         assert g.solve_iter_l2f(w * 100, (w + 1) * 100, vec, 0) == o.solve_iter_l2f(w * 100, (w + 1) * 100, vec, 0)
@@ -126,9 +125,8 @@ def test_batch_matches_single_instances():
     B = LpBatch(insts)
     B.solve_init()
     rets = B.solve_iter(0, 20000)
-    T = B.config()["threads"]
     for i, I in enumerate(insts):
-        o = make_oracle(I, O.ORDER_GPU, T)
+        o = oracle_for(B, i, I)
         ro = o.solve_iter(0, 20000)
         assert rets[i] == ro
         assert B.counters(i) == (o.total_outer_iters, o.total_pcg_iters)
