@@ -1023,3 +1023,18 @@ int lpo_get_pcg_trace(const lpo_t *o, int *out, int cap) {
     for (int i = 0; i < c; i++) out[i] = o->pcg_trace[i];
     return c;
 }
+
+/* ---- stand-alone kernels of the iteration, for known-answer tests ---- */
+/* project_box LPcpp:409-421 */
+void lpo_project_box(int n, const double *x, double *y) {
+    for (int i = 0; i < n; i++) y[i] = x[i] > 1 ? 1 : (x[i] < 0 ? 0 : x[i]);
+}
+/* project_shifted_Lp_ball LPcpp:423-428 with p = 2 (Eigen reduction order) */
+void lpo_project_shifted_lp_ball(int n, const double *x, double *y) {
+    double *t = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    for (int i = 0; i < n; i++) { y[i] = x[i] - 0.5; t[i] = y[i] * y[i]; }
+    double normp_shift = sqrt(redux_sum_eigen(t, n));
+    double c1 = pow((double)n, 1.0 / 2), c2 = 2 * normp_shift;
+    for (int i = 0; i < n; i++) y[i] = y[i] * c1 / c2 + 0.5;
+    free(t);
+}

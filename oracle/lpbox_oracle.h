@@ -89,6 +89,10 @@ double lpo_get_scalar(const lpo_t *o, const char *name);
 /* per-outer-iteration PCG iteration counts of the LAST lpo_iters/_l2f call; returns count copied */
 int    lpo_get_pcg_trace(const lpo_t *o, int *out, int cap);
 
+/* stand-alone pieces for known-answer tests: project_box LPcpp:409-421, project_shifted_Lp_ball LPcpp:423-428 (p = 2) */
+void lpo_project_box(int n, const double *x, double *y);
+void lpo_project_shifted_lp_ball(int n, const double *x, double *y);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,6 +67,8 @@ def lib():
     L.lpo_get_scalar.argtypes = [C.c_void_p, C.c_char_p]
     L.lpo_get_scalar.restype = C.c_double
     L.lpo_get_pcg_trace.argtypes = [C.c_void_p, _ip, C.c_int]
+    L.lpo_project_box.argtypes = [C.c_int, _dp, _dp]
+    L.lpo_project_shifted_lp_ball.argtypes = [C.c_int, _dp, _dp]
     _lib = L
     return L
 
@@ -217,3 +219,17 @@ def load_lp_batch(path):
                         b=-1.0 * d["price"][pr:pr + n]))
         cp += n + 1; ri += nnz; pr += n
     return out
+
+
+def project_box(x):
+    x = np.ascontiguousarray(x, np.float64)
+    y = np.zeros_like(x)
+    lib().lpo_project_box(len(x), x, y)
+    return y
+
+
+def project_shifted_lp_ball(x):
+    x = np.ascontiguousarray(x, np.float64)
+    y = np.zeros_like(x)
+    lib().lpo_project_shifted_lp_ball(len(x), x, y)
+    return y

@@ -1,0 +1,83 @@
+"""CPU tests of the boundary: the C-ABI library loads, exports every symbol include/lpbox_hip.h declares, validates its
+arguments on the host, and refuses to compute without a HIP device (no fallback).  No compute call needs a GPU here."""
+import inspect
+import os
+import re
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, lp_instances
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "lpbox_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(lpbox_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    import ctypes
+    from lpbox_hip import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = declared_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"liblpbox_hip.so does not export {n}"
+    assert set(names) == set(_lib.SYMBOLS), "ctypes table and header disagree"
+    assert _lib.load().lpbox_version().startswith(b"lpbox_hip")
+
+
+def test_python_class_mirrors_the_pyx_surface():
+    """Method names and arities of LinerProgramming/LinearProgramming/cython_solver/lpbox.pyx:7-76."""
+    from LinearProgramming.cython_solver import lpbox
+    want = {"read_File": 3, "solve_init": 0, "solve_iter": 2, "cal_Obj": 0, "get_curBinObj": 0, "solve_iter_l2f": 4,
+            "get_x_iters_1d": 1, "get_x_iters_2d": 1, "get_n": 0, "get_iter": 0, "get_x_sol": 1, "get_final_x_sol": 1,
+            "check_infeasible_lpbox": 0, "check_infeasible_l2f": 0}
+    for name, nargs in want.items():
+        fn = getattr(lpbox.PyLPboxADMMsolver, name)
+        params = [p for p in inspect.signature(fn).parameters.values() if p.name != "self"]
+        assert len(params) == nargs, name
+    with pytest.raises(TypeError):
+        lpbox.PyLPboxADMMsolver(5, 0.5)     # the 2-argument __cinit__ (pyx:10-11) is shadowed by the 1-argument one
+
+
+def test_host_side_validation_and_no_cpu_fallback():
+    from lpbox_hip import _lib
+    from lpbox_hip.lp import LpBatch, LpboxError, PyLPboxADMMsolver
+    I = lp_instances("lp_20_60_seed0.npz")[0]
+    b = LpBatch(batch=1)
+    with pytest.raises(LpboxError, match="row index"):
+        bad = I["rowidx"].copy(); bad[0] = 10 ** 6
+        b.set_problem(0, I["n"], I["l"], I["colptr"], bad, I["b"])
+    with pytest.raises(LpboxError, match="!= 1"):
+        b.set_problem(0, I["n"], I["l"], I["colptr"], I["rowidx"], I["b"], vals=2 * np.ones(len(I["rowidx"])))
+    with pytest.raises(LpboxError, match="range"):
+        b.set_problem(3, I["n"], I["l"], I["colptr"], I["rowidx"], I["b"])
+    b.set_problem(0, I["n"], I["l"], I["colptr"], I["rowidx"], I["b"])
+    assert b.get_org_n(0) == I["n"] and b.get_l(0) == I["l"]
+    with pytest.raises(LpboxError, match="solve_init"):
+        b.solve_iter(0, 10)
+    s = PyLPboxADMMsolver(0)
+    with pytest.raises(LpboxError, match="cannot open"):
+        s.data_root = "/nonexistent"
+        s.read_File(1, 100, 500)
+    s.data_root = GOLDEN
+    s.read_File(1, 100, 500)                  # <root>/instance/100_500/instance_1_{C,b}.txt (LPcpp:2492-2494)
+    assert s.batch.get_org_n(0) == 500 and s.batch.get_l(0) == 189
+    if _lib.load().lpbox_device_count() == 0:
+        with pytest.raises(LpboxError, match="no HIP device"):
+            s.solve_init()                    # the product path fails loudly without its GPU
+
+
+def test_shard_range_partitions():
+    from lpbox_hip.dist import shard_range
+    for total in (0, 1, 7, 256, 2048):
+        for world in (1, 2, 3, 8):
+            blocks = [shard_range(total, world, r) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == total
+            assert all(blocks[i][1] == blocks[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in blocks]
+            assert max(sizes) - min(sizes) <= 1

@@ -1,6 +1,6 @@
 import sys, os, ctypes as C
 os.environ["LPBOX_LIB_VARIANT"]="stamps"
-sys.path.insert(0,'accelerated-lpbox-admm_amd'); sys.path.insert(0,'.')
+ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,os.path.join(ROOT,'accelerated-lpbox-admm_amd')); sys.path.insert(0,ROOT)
 import numpy as np
 from bench import load_instances, FIXTURE
 from lpbox_hip.lp import LpBatch

@@ -1,6 +1,6 @@
 """Tuning helper: time a fixed window of iterations (no instance converges that early) on the 256-instance batch."""
 import sys, os, time
-sys.path.insert(0,'accelerated-lpbox-admm_amd'); sys.path.insert(0,'.')
+ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,os.path.join(ROOT,'accelerated-lpbox-admm_amd')); sys.path.insert(0,ROOT)
 import numpy as np
 from bench import load_instances, FIXTURE, byte_model
 from lpbox_hip.lp import LpBatch
