@@ -6,6 +6,7 @@
 //                      LPh   = .../cython_solver/LPboxADMMsolver.h, pxd = .../cython_solver/LPboxADMMsolver.pxd
 #include "../../include/lpbox_hip.h"
 #include "lpbox_lp.h"
+#include "lpbox_capi_internal.h"
 
 #include <algorithm>
 #include <cmath>
@@ -29,6 +30,20 @@ int fail(int code, const char *fmt, ...) {
     g_err = buf;
     return code;
 }
+
+}  // namespace
+
+int lpbox_fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+namespace {
 
 #define HIPCHK(expr)                                                                                   \
     do {                                                                                               \
@@ -70,6 +85,7 @@ struct DevBuf {
 
 struct lpbox_solver {
     int flavour = LPBOX_FLAVOUR_LP, B = 0, print_info = 0, device = 0;
+    SegSolver *seg = nullptr;         // flavour SEG: everything lives in the segmentation host object
     std::vector<LpInstance> inst;
     bool finalized = false, inited = false;
     int NS = 0, LS = 0, ZS = 0, T = 0, EPT = 0;
@@ -367,18 +383,20 @@ int lpbox_set_device(int device) {
 }
 
 lpbox_t *lpbox_create(int flavour, int batch, int print_info) {
-    if (batch <= 0 || (flavour != LPBOX_FLAVOUR_LP)) {
+    if (batch <= 0 || (flavour != LPBOX_FLAVOUR_LP && flavour != LPBOX_FLAVOUR_SEG) || (flavour == LPBOX_FLAVOUR_SEG && batch != 1)) {
         fail(LPBOX_E_BADARG, "lpbox_create: unsupported flavour %d or batch %d", flavour, batch);
         return nullptr;
     }
     lpbox_t *h = new lpbox_solver();
     h->flavour = flavour; h->B = batch; h->print_info = print_info; h->device = g_device;
-    h->inst.resize(batch);
+    if (flavour == LPBOX_FLAVOUR_SEG) h->seg = segc_create(print_info, g_device);
+    else h->inst.resize(batch);
     return h;
 }
 
 void lpbox_destroy(lpbox_t *h) {
     if (!h) return;
+    if (h->seg) { segc_destroy(h->seg); delete h; return; }
     if (h->finalized) (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->rs_ptr.release(); h->cs_ptr.release(); h->isc.release(); h->ctl.release(); h->left_idx.release(); h->xi_rows.release();
@@ -394,6 +412,7 @@ void lpbox_destroy(lpbox_t *h) {
 
 int lpbox_set_problem_lp(lpbox_t *h, int idx, int n, int l, int nnz, const int *colptr, const int *rowidx,
                          const double *vals, const double *b, const double *f) {
+    if (valid_handle(h) && h->seg) return fail(LPBOX_E_STATE, "this entry point belongs to the LP flavour");
     int rc = check_idx(h, idx);
     if (rc) return rc;
     return set_instance(h, idx, n, l, nnz, colptr, rowidx, vals, b, f);
@@ -401,6 +420,7 @@ int lpbox_set_problem_lp(lpbox_t *h, int idx, int n, int l, int nnz, const int *
 
 // readSparseMat LPcpp:2416-2444, readDenseVec :2407-2414, readFile :2446-2545
 int lpbox_read_files_lp(lpbox_t *h, int idx, const char *path_C, const char *path_b, int k) {
+    if (valid_handle(h) && h->seg) return fail(LPBOX_E_STATE, "this entry point belongs to the LP flavour");
     int rc = check_idx(h, idx);
     if (rc) return rc;
     if (!path_C || !path_b) return fail(LPBOX_E_BADARG, "null path");
@@ -456,6 +476,7 @@ int lpbox_read_file(lpbox_t *h, int idx, const char *root, int i, int k, int j) 
 }
 
 int lpbox_init(lpbox_t *h) {
+    if (valid_handle(h) && h->seg) return segc_init(h->seg);
     if (!valid_handle(h)) return fail(LPBOX_E_BADHANDLE, "bad handle");
     int rc = finalize(h);
     if (rc) return rc;
@@ -476,6 +497,7 @@ int lpbox_init(lpbox_t *h) {
 }
 
 int lpbox_iterate(lpbox_t *h, int iter_start, int iter_end, int *rets) {
+    if (valid_handle(h) && h->seg) return fail(LPBOX_E_STATE, "this entry point belongs to the LP flavour");
     if (!valid_handle(h)) return fail(LPBOX_E_BADHANDLE, "bad handle");
     if (!h->inited) return fail(LPBOX_E_STATE, "solve_init has not been called");
     int rc = use_device(h);
@@ -490,6 +512,13 @@ int lpbox_iterate(lpbox_t *h, int iter_start, int iter_end, int *rets) {
 
 int lpbox_iterate_l2f(lpbox_t *h, int iter_start, int iter_end, const double *vec, long vec_stride, const int *nums,
                       int *rets) {
+    if (valid_handle(h) && h->seg) {
+        int ret = 0;
+        int rc = segc_l2f(h->seg, iter_start, iter_end, vec, nums ? nums[0] : 0, &ret);
+        if (rc < 0) return rc;
+        if (rets) rets[0] = ret;
+        return ret;
+    }
     if (!valid_handle(h)) return fail(LPBOX_E_BADHANDLE, "bad handle");
     if (!h->inited) return fail(LPBOX_E_STATE, "solve_init has not been called");
     const int ws = iter_end - iter_start;
@@ -566,6 +595,7 @@ int lpbox_iterate_l2f(lpbox_t *h, int iter_start, int iter_end, const double *ve
 }
 
 int lpbox_get_n(lpbox_t *h, int idx) {
+    if (valid_handle(h) && h->seg) return segc_get_n(h->seg);
     int rc = check_idx(h, idx);
     if (rc) return rc;
     if (!h->inited) return h->inst[idx].n;
@@ -573,6 +603,7 @@ int lpbox_get_n(lpbox_t *h, int idx) {
 }
 
 int lpbox_get_org_n(lpbox_t *h, int idx) {
+    if (valid_handle(h) && h->seg) return segc_get_org_n(h->seg);
     int rc = check_idx(h, idx);
     if (rc) return rc;
     return h->inst[idx].n;
@@ -585,6 +616,7 @@ int lpbox_get_l(lpbox_t *h, int idx) {
 }
 
 int lpbox_get_iter(lpbox_t *h, int idx) {
+    if (valid_handle(h) && h->seg) return segc_get_iter(h->seg);
     int rc = check_idx(h, idx);
     if (rc) return rc;
     if (!h->inited) return 0;
@@ -592,6 +624,7 @@ int lpbox_get_iter(lpbox_t *h, int idx) {
 }
 
 int lpbox_get_x_iters(lpbox_t *h, int idx, int ws, double *out) {
+    if (valid_handle(h) && h->seg) return segc_get_x_iters(h->seg, ws, out);
     int rc = check_idx(h, idx);
     if (rc) return rc;
     if (!h->xi_valid) return fail(LPBOX_E_STATE, "solve_iter_l2f has not been called");
@@ -620,6 +653,7 @@ int lpbox_get_x_iters(lpbox_t *h, int idx, int ws, double *out) {
 }
 
 int lpbox_get_x_sol(lpbox_t *h, int idx, double *out) {
+    if (valid_handle(h) && h->seg) return segc_get_x_sol(h->seg, out);
     int rc = check_idx(h, idx);
     if (rc) return rc;
     if (!h->inited || !out) return fail(LPBOX_E_STATE, "not initialised");
@@ -701,6 +735,7 @@ int lpbox_check_infeasible_l2f(lpbox_t *h, int idx) {                       // L
 }
 
 int lpbox_get_config(lpbox_t *h, int *threads, int *elems_per_thread, int *lds_bytes) {
+    if (valid_handle(h) && h->seg) return segc_get_config(h->seg, threads, elems_per_thread, lds_bytes);
     if (!valid_handle(h)) return fail(LPBOX_E_BADHANDLE, "bad handle");
     int rc = finalize(h);
     if (rc) return rc;
@@ -733,6 +768,7 @@ int lpbox_get_row_split(lpbox_t *h, int idx, int *lanes_of_row) {
 }
 
 int lpbox_get_counters(lpbox_t *h, int idx, long long *outer_iters, long long *pcg_iters) {
+    if (valid_handle(h) && h->seg) return segc_get_counters(h->seg, outer_iters, pcg_iters);
     int rc = check_idx(h, idx);
     if (rc) return rc;
     if (!h->inited) return fail(LPBOX_E_STATE, "not initialised");
@@ -742,6 +778,7 @@ int lpbox_get_counters(lpbox_t *h, int idx, long long *outer_iters, long long *p
 }
 
 int lpbox_get_stop(lpbox_t *h, int idx, int *reason, int *plain_iter_plus1) {
+    if (valid_handle(h) && h->seg) return segc_get_stop(h->seg, reason, plain_iter_plus1);
     int rc = check_idx(h, idx);
     if (rc) return rc;
     if (!h->inited) return fail(LPBOX_E_STATE, "not initialised");
@@ -751,6 +788,7 @@ int lpbox_get_stop(lpbox_t *h, int idx, int *reason, int *plain_iter_plus1) {
 }
 
 int lpbox_kernel_time(lpbox_t *h, double *ms_total, long long *launches, int reset) {
+    if (valid_handle(h) && h->seg) return segc_kernel_time(h->seg, ms_total, launches, reset);
     if (!valid_handle(h)) return fail(LPBOX_E_BADHANDLE, "bad handle");
     if (ms_total) *ms_total = h->kernel_ms;
     if (launches) *launches = h->launches;
@@ -759,6 +797,7 @@ int lpbox_kernel_time(lpbox_t *h, double *ms_total, long long *launches, int res
 }
 
 int lpbox_debug_get_vec(lpbox_t *h, int idx, const char *name, double *out, int cap) {
+    if (valid_handle(h) && h->seg) return segc_debug_vec(h->seg, name, out, cap);
     int rc = check_idx(h, idx);
     if (rc) return rc;
     if (!h->inited || !name || !out) return fail(LPBOX_E_STATE, "not initialised");
@@ -797,6 +836,7 @@ int lpbox_debug_get_stamps(lpbox_t *h, int idx, unsigned long long *out16) {
 }
 
 int lpbox_debug_get_scalar(lpbox_t *h, int idx, const char *name, double *out) {
+    if (valid_handle(h) && h->seg) return segc_debug_scalar(h->seg, name, out);
     int rc = check_idx(h, idx);
     if (rc) return rc;
     if (!h->inited || !name || !out) return fail(LPBOX_E_STATE, "not initialised");
@@ -811,6 +851,50 @@ int lpbox_debug_get_scalar(lpbox_t *h, int idx, const char *name, double *out) {
     };
     for (auto &e : tab) if (!strcmp(e.n, name)) { *out = e.v; return LPBOX_OK; }
     return fail(LPBOX_E_BADARG, "unknown scalar '%s'", name);
+}
+
+// ---- segmentation flavour (SEG pxd = Segmentation/Segmentation/cython/src/LPboxADMMsolver.pxd) ----
+static int seg_handle(lpbox_t *h) {
+    if (!valid_handle(h)) return fail(LPBOX_E_BADHANDLE, "bad handle");
+    if (!h->seg) return fail(LPBOX_E_STATE, "this entry point belongs to the segmentation flavour");
+    return LPBOX_OK;
+}
+
+int lpbox_set_problem_bqp(lpbox_t *h, int n, int nnz, const int *rowptr, const int *colidx, const double *vals,
+                          const double *b, double c, int rows, int cols) {
+    int rc = seg_handle(h);
+    if (rc) return rc;
+    return segc_set_problem(h->seg, n, nnz, rowptr, colidx, vals, b, c, rows, cols);
+}
+
+int lpbox_seg_set_image(lpbox_t *h, const unsigned char *gray, int rows, int cols, int num_nodes) {
+    int rc = seg_handle(h);
+    if (rc) return rc;
+    return segc_set_image(h->seg, gray, rows, cols, num_nodes);
+}
+
+int lpbox_seg_legacy(lpbox_t *h, int *energy) {
+    int rc = seg_handle(h);
+    if (rc) return rc;
+    return segc_legacy(h->seg, energy);
+}
+
+int lpbox_seg_get_obj(lpbox_t *h, double *out) {
+    int rc = seg_handle(h);
+    if (rc) return rc;
+    return segc_get_obj(h->seg, out);
+}
+
+int lpbox_seg_get_shape(lpbox_t *h, int *rows, int *cols) {
+    int rc = seg_handle(h);
+    if (rc) return rc;
+    return segc_get_shape(h->seg, rows, cols);
+}
+
+int lpbox_seg_get_problem(lpbox_t *h, int *n, int *nnz, int *rowptr, int *colidx, double *vals, double *b, double *c) {
+    int rc = seg_handle(h);
+    if (rc) return rc;
+    return segc_get_problem(h->seg, n, nnz, rowptr, colidx, vals, b, c);
 }
 
 }  // extern "C"

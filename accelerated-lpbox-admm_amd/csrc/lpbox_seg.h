@@ -1,0 +1,74 @@
+// lpbox_seg.h -- internal device-side layout of the SEGMENTATION flavour (unconstrained BQP min x'Ax + b'x, x in {0,1}^n;
+// SEGcpp = Segmentation/Segmentation/cython/src/LPboxADMMsolver.cpp).  Not part of the C-ABI.
+//
+// One instance has n ~ 1e4 .. 1e6 variables: far too large for one workgroup, so every vector lives in HBM (L2 /
+// Infinity-Cache resident at these sizes) and one ADMM iteration is a short chain of kernels separated by the grid-wide
+// dependencies of the algorithm (sparse product -> dot product -> update).  Workgroup g owns the CHUNK = T*EPT consecutive
+// variables [g*CHUNK, (g+1)*CHUNK); reductions are two-level (block tree per workgroup -> G partials -> the same block tree
+// over the partials, recomputed by every consumer workgroup), which the CPU oracle mirrors exactly.
+// All control state is on the device (SegState, ping-ponged between kernels), so a window of iterations is a static
+// sequence of launches that a hipGraph replays.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// hyper-parameters, hard-coded as in ADMM_bqp_unconstrained_init (SEGcpp:659-672)
+#define SEG_STD_THRESHOLD 1e-6                 // :659
+#define SEG_GAMMA0        1.0                  // :660
+#define SEG_GAMMA_FACTOR  0.99                 // :661
+#define SEG_RHO0          5.0                  // :662
+#define SEG_LEARNING_FACT (1 + 3.0 / 100)      // :663
+#define SEG_HIST          5                    // :665 history_size
+#define SEG_RHO_STEP      5                    // :666
+#define SEG_STOP_THRESHOLD 1e-3                // :668
+#define SEG_MAX_ITERS     10000                // :669
+#define SEG_PCG_TOL       1e-3                 // :671
+#define SEG_PCG_MAXITERS  1000                 // :672
+#define SEG_XITERS_COLS   10                   // :924
+
+#define SEG_T 256
+#define SEG_NPART 8        // partial-sum slots per phase
+
+enum { SEG_HALT_NONE = 0, SEG_HALT_STOP = 1, SEG_HALT_WINDOW = 2, SEG_HALT_PCG_MORE = 3, SEG_HALT_ALLFIXED = 4 };
+enum { SEG_STOP_NONE = 0, SEG_STOP_XYY = 1, SEG_STOP_OBJSTD = 2, SEG_STOP_ALLFIXED = 4 };
+
+struct SegState {
+    // scalars of the reference object (SEGh)
+    double rho1, rho2, prev_rho1, prev_rho2, gamma_val, rcr, std_obj, cur_obj, best_bin_obj, cvg1, cvg2, obj_val, c1;
+    double hist[SEG_HIST];
+    // PCG scalars carried between kernels
+    double threshold, absNew, rhsNorm2;
+    int rhoUpdated, hist_n, n_live;
+    int iter;            // next outer iteration to run
+    int iter_end;        // window end (exclusive)
+    int phase;           // 0 = between iterations, 1 = inside an iteration (after prep), 2 = PCG running, 3 = PCG done
+    int pcg_k;           // PCG iterations finished in the current outer iteration
+    int pcg_done;
+    int have_prev;       // an iteration's partE is waiting to be finalised
+    int halt, stop, ret, l2f, cc;
+    int pcg_total, outer_total, last_pcg, legacy_iter_p1;
+    int dinv_stale;      // a fix rebuilt the diagonal while no rho update was pending (stale preconditioner = UB in the reference)
+};
+
+struct SegDev {
+    int n, nnz, G, EPT;                    // G workgroups of SEG_T threads, EPT slots each
+    const int *rowptr, *colidx; const double *vals;    // A_ptr (row-major, ascending columns; SEGh:17)
+    double *x, *y1, *y2, *z1, *z2, *b, *rhs, *r, *z, *tmp, *dinv, *td, *p0, *p1;
+    uint8_t *live;          // 1 live, 0 fixed (x = 0 there; the fixed value is kept in fixval)
+    uint8_t *fixval;
+    const uint8_t *newfix;  // consumed by the fix kernel: 0 none, 1 fix to 0, 2 fix to 1
+    double *part;           // [phase(5)][SEG_NPART][Gmax]
+    double *xhist; int ws_cap;
+    SegState *st;           // st[0], st[1] ping-pong
+};
+
+hipError_t seg_launch_init(const SegDev &d, double c1, hipStream_t s);
+// Every launch below reads st[*parity], writes st[*parity ^ 1] and flips *parity.
+hipError_t seg_launch_set_window(const SegDev &d, int iter_start, int iter_end, int l2f, int *parity, hipStream_t s);
+hipError_t seg_launch_fix(const SegDev &d, int n_live_new, double c1_new, int *parity, hipStream_t s);
+// `iters` outer iterations, each = prep, yrhs, resid, kmax x (matvec, update), post  (an even number of launches)
+hipError_t seg_enqueue_iterations(const SegDev &d, int iters, int kmax, int *parity, hipStream_t s);
+hipError_t seg_enqueue_pcg_more(const SegDev &d, int pairs, int *parity, hipStream_t s);   // resume a stalled PCG, then post
+hipError_t seg_enqueue_finalize(const SegDev &d, int *parity, hipStream_t s);              // finalise the last iteration only
+hipError_t seg_launch_copy(const SegDev &d, int *parity, hipStream_t s);                      // state copy (parity flip) only
+hipError_t seg_launch_pack_xiters(const SegDev &d, const int *live_idx, int rows, int ws, double *out, hipStream_t s);

@@ -1,0 +1,475 @@
+// lpbox_seg_kernels.hip -- gfx950 kernels of the SEGMENTATION flavour (unconstrained BQP, SEGcpp:658-1380).
+//
+// n ~ 1e4..1e6, so the vectors live in HBM / L2 and one ADMM iteration is a chain of kernels cut at the algorithm's
+// grid-wide dependencies:
+//   prep    : finalise the previous iteration (stop tests, rho schedule, objective history), partial ||x+z2/rho2-1/2||^2
+//   yrhs    : y1, y2, diagonal/preconditioner refresh, rhs, PCG start x0 = y1
+//   resid   : r = rhs - (2A+(rho1+rho2)I) x0,  p = r/diag, partials rhs.rhs, r.r, r.p
+//   matvec  : [beta, p = z + beta p]  tmp = M p, partial p.tmp          \  one PCG iteration = 2 launches: the p update of
+//   update  : alpha, x += alpha p, r -= alpha tmp, z = r/diag, partials /  iteration k is recomputed on the fly for the
+//                                                                          gathered neighbours inside matvec k
+//   post    : duals z1,z2, A x and A round(x) (objective), the five norms / dot partials, x_iters column
+// Each kernel reads the control state st[in], every workgroup re-derives the same scalar decisions from the same partial
+// sums (two-level fixed tree, bit-reproducible), and thread 0 of workgroup 0 writes st[out]; a halted / finished state makes
+// every later kernel of the replayed graph fall through.  Sparse rows are summed by one lane in ascending column order
+// (Eigen's row-major product, SEGh:17), no FMA contraction, IEEE divide/sqrt -- as in the LP kernels.
+#include "lpbox_seg.h"
+#include "lpbox_dev_common.h"
+
+#include <float.h>
+
+namespace {
+
+constexpr int T = SEG_T;
+enum { PH_A = 0, PH_B = 1, PH_C = 2, PH_D = 3, PH_E = 4, PH_COUNT = 5 };
+
+__device__ __forceinline__ double *part_ptr(const SegDev &d, int phase, int v) {
+    return d.part + ((size_t)(phase * SEG_NPART + v)) * (size_t)d.G;
+}
+
+// every workgroup: total of the G workgroup partials of NV values (second level of the fixed tree)
+template <int NV>
+__device__ __forceinline__ void final_sums(const SegDev &d, int phase, double (&out)[NV], double *red, int &parity) {
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        const double *p = part_ptr(d, phase, k);
+        double a = 0.0;
+        for (int e = threadIdx.x; e < d.G; e += T) a = a + p[e];
+        out[k] = a;
+    }
+    block_sum<T, NV>(out, red, parity);
+}
+
+template <int NV>
+__device__ __forceinline__ void store_partials(const SegDev &d, int phase, double (&v)[NV], double *red, int &parity) {
+    block_sum<T, NV>(v, red, parity);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; k++) part_ptr(d, phase, k)[blockIdx.x] = v[k];
+    }
+}
+
+__device__ __forceinline__ void write_state(const SegDev &d, int out, const SegState &s) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) d.st[out] = s;
+}
+
+// (2A + (rho1+rho2) I) row i times a gathered vector: diagonal entry = td[i], off-diagonal = 2*A_ik (SEGcpp:784-786)
+template <typename GET>
+__device__ __forceinline__ double tm_row(const SegDev &d, int i, GET get) {
+    double tmp = 0;
+    const int k1 = d.rowptr[i + 1];
+    const double tdi = d.td[i];
+    for (int k = d.rowptr[i]; k < k1; k++) {
+        const int c = d.colidx[k];
+        const double val = (c == i) ? tdi : 2 * d.vals[k];
+        tmp += val * get(c);
+    }
+    double res = 0.0;
+    res += 1.0 * tmp;
+    return res;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(T) seg_k_init(SegDev d, double c1) {      // ADMM_bqp_unconstrained_init SEGcpp:658-810
+    for (int s = 0; s < d.EPT; s++) {
+        const int i = blockIdx.x * (T * d.EPT) + s * T + threadIdx.x;
+        if (i >= d.n) continue;
+        d.x[i] = 0.0; d.y1[i] = 0.0; d.y2[i] = 0.0; d.z1[i] = 0.0; d.z2[i] = 0.0;   // :762-777
+        d.live[i] = 1; d.fixval[i] = 0;
+        double aii = 0.0;
+        for (int k = d.rowptr[i]; k < d.rowptr[i + 1]; k++) if (d.colidx[k] == i) aii = d.vals[k];
+        double t = 2 * aii;
+        t += SEG_RHO0 + SEG_RHO0;                                           // temp_mat.diagonal() += rho1 + rho2 (:785)
+        d.td[i] = t;
+        d.dinv[i] = 1.0; d.r[i] = 0.0; d.z[i] = 0.0; d.tmp[i] = 0.0; d.p0[i] = 0.0; d.p1[i] = 0.0; d.rhs[i] = 0.0;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        SegState s;
+        memset(&s, 0, sizeof(s));
+        s.rho1 = s.rho2 = s.prev_rho1 = s.prev_rho2 = SEG_RHO0;
+        s.gamma_val = SEG_GAMMA0; s.std_obj = 1.0; s.rhoUpdated = 1;
+        s.best_bin_obj = 0.0 + 0.0;                                         // compute_cost(x = 0) (:792)
+        s.n_live = d.n; s.c1 = c1;
+        d.st[0] = s; d.st[1] = s;
+    }
+}
+
+__global__ void seg_k_set_window(SegDev d, int in, int out, int iter_start, int iter_end, int l2f) {
+    SegState s = d.st[in];
+    s.iter = iter_start; s.iter_end = iter_end; s.l2f = l2f; s.cc = 0; s.ret = 0; s.stop = SEG_STOP_NONE;
+    if (s.halt != SEG_HALT_ALLFIXED) s.halt = SEG_HALT_NONE;
+    d.st[out] = s;
+}
+
+__global__ void seg_k_resume(SegDev d, int in, int out) {
+    SegState s = d.st[in];
+    if (s.halt == SEG_HALT_PCG_MORE) s.halt = SEG_HALT_NONE;
+    d.st[out] = s;
+}
+
+// early fixing as a mask (SEGcpp:927-1062): fixed variables leave the problem, b := 2*Mb*x2 + b1, temp_mat rebuilt
+__global__ void __launch_bounds__(T) seg_k_fix(SegDev d, int in, int out, int n_live_new, double c1_new) {
+    SegState s = d.st[in];
+    for (int q = 0; q < d.EPT; q++) {
+        const int i = blockIdx.x * (T * d.EPT) + q * T + threadIdx.x;
+        if (i >= d.n) continue;
+        const int nf = d.newfix[i];
+        if (nf) { d.live[i] = 0; d.fixval[i] = nf == 2 ? 1 : 0; d.x[i] = 0.0; d.p0[i] = 0.0; d.p1[i] = 0.0; d.z[i] = 0.0; d.r[i] = 0.0; continue; }
+        if (!d.live[i]) continue;
+        if (n_live_new == 0) continue;
+        double tmp = 0, aii = 0.0;
+        for (int k = d.rowptr[i]; k < d.rowptr[i + 1]; k++) {
+            const int c = d.colidx[k];
+            if (c == i) aii = d.vals[k];
+            const int nfc = d.newfix[c];
+            if (nfc) tmp += d.vals[k] * (nfc == 2 ? 1.0 : 0.0);            // Mb * x2, ascending column (:1051)
+        }
+        double res = 0.0;
+        res += 1.0 * tmp;
+        d.b[i] = 2 * res + d.b[i];                                          // :1052
+        double t = 2 * aii;
+        t += s.rho1 + s.rho2;                                               // :1054-1057
+        d.td[i] = t;
+    }
+    if (n_live_new == 0) { s.ret = 1; s.stop = SEG_STOP_ALLFIXED; s.halt = SEG_HALT_ALLFIXED; s.n_live = 0; }   // :1028-1032
+    else { s.n_live = n_live_new; s.c1 = c1_new; s.dinv_stale = 1; }
+    write_state(d, out, s);
+}
+
+// prep: finalise the previous iteration, then start the next one
+__global__ void __launch_bounds__(T) seg_k_prep(SegDev d, int in, int out, int do_prep) {
+    __shared__ double red[2 * RED_MAXV * RED_MAXW];
+    int parity = 0;
+    SegState s = d.st[in];
+    if (!s.halt && s.have_prev) {
+        double e[5];
+        final_sums<5>(d, PH_E, e, red, parity);                              // x.x, |x-y1|^2, |x-y2|^2, x.Ax, b.x
+        double e2[2];
+        {
+            const double *p5 = part_ptr(d, PH_E, 5), *p6 = part_ptr(d, PH_E, 6);
+            double a = 0.0, b2 = 0.0;
+            for (int q = threadIdx.x; q < d.G; q += T) { a = a + p5[q]; b2 = b2 + p6[q]; }
+            e2[0] = a; e2[1] = b2;
+            block_sum<T, 2>(e2, red, parity);                                // xb.A xb, b.xb
+        }
+        s.have_prev = 0;
+        const int it = s.iter;
+        const double xn = sqrt(e[0]);
+        const double t0 = xn < 2.2204e-16 ? 2.2204e-16 : xn;
+        s.cvg1 = sqrt(e[1]) / t0; s.cvg2 = sqrt(e[2]) / t0;
+        const double bin_cost = e2[0] + e2[1];                               // compute_cost(round(x)) (:1167 / :1372)
+        bool stopped = false;
+        if (s.cvg1 <= SEG_STOP_THRESHOLD && s.cvg2 <= SEG_STOP_THRESHOLD) {  // :1127 / :1282
+            if (s.l2f) s.ret = 1;
+            s.stop = SEG_STOP_XYY; stopped = true;
+        } else {
+            if ((it + 1) % SEG_RHO_STEP == 0) {                              // :1137-1145
+                s.prev_rho1 = s.rho1; s.prev_rho2 = s.rho2;
+                s.rho1 = SEG_LEARNING_FACT * s.rho1; s.rho2 = SEG_LEARNING_FACT * s.rho2;
+                const double g = s.gamma_val * SEG_GAMMA_FACTOR;
+                s.gamma_val = g < 1.0 ? 1.0 : g;
+                s.rhoUpdated = 1; s.rcr = SEG_LEARNING_FACT - 1.0;
+            }
+            s.obj_val = e[3] + e[4];                                         // compute_cost(x) (:1148)
+            if (s.hist_n < SEG_HIST) s.hist[s.hist_n] = s.obj_val;
+            else { for (int k = 0; k < SEG_HIST - 1; k++) s.hist[k] = s.hist[k + 1]; s.hist[SEG_HIST - 1] = s.obj_val; }
+            if (s.hist_n < 0x3fffffff) s.hist_n++;
+            if (s.hist_n >= SEG_HIST) {
+                double mean = 0;
+                for (int k = 0; k < SEG_HIST; k++) mean += s.hist[k];
+                mean /= (double)SEG_HIST;
+                double dev = 0;
+                for (int k = 0; k < SEG_HIST; k++) dev += (s.hist[k] - mean) * (s.hist[k] - mean);
+                dev /= (double)(SEG_HIST - 1);
+                const double sd = dev == 0 ? 0.0 : sqrt(dev);
+                s.std_obj = sd / fabs(s.hist[SEG_HIST - 1]);
+            }
+            if (s.std_obj <= SEG_STD_THRESHOLD) { if (s.l2f) s.ret = 1; s.stop = SEG_STOP_OBJSTD; stopped = true; }
+            else {
+                s.cur_obj = bin_cost;
+                if (s.best_bin_obj >= s.cur_obj) s.best_bin_obj = s.cur_obj;
+            }
+        }
+        if (stopped) {
+            s.halt = SEG_HALT_STOP;
+            if (!s.l2f) { s.cur_obj = bin_cost; s.legacy_iter_p1 = it + 1; }   // legacy epilogue (:1371-1376)
+        } else s.iter = it + 1;
+    }
+    if (!s.halt && s.iter >= s.iter_end) { s.halt = SEG_HALT_WINDOW; if (!s.l2f) s.legacy_iter_p1 = s.iter + 1; }
+    if (s.halt || !do_prep) { write_state(d, out, s); return; }
+    double pa[1] = {0.0};
+    for (int q = 0; q < d.EPT; q++) {
+        const int i = blockIdx.x * (T * d.EPT) + q * T + threadIdx.x;
+        double c = 0.0;
+        if (i < d.n && d.live[i]) { const double u = (d.x[i] + d.z2[i] / s.rho2) - 0.5; c = u * u; }
+        pa[0] = pa[0] + c;
+    }
+    store_partials<1>(d, PH_A, pa, red, parity);
+    s.phase = 1;
+    write_state(d, out, s);
+}
+
+__global__ void __launch_bounds__(T) seg_k_yrhs(SegDev d, int in, int out) {
+    __shared__ double red[2 * RED_MAXV * RED_MAXW];
+    int parity = 0;
+    SegState s = d.st[in];
+    if (s.halt) { write_state(d, out, s); return; }
+    double a[1];
+    final_sums<1>(d, PH_A, a, red, parity);
+    const double c2 = 2 * sqrt(a[0]);
+    const bool refresh = s.iter != 0 && s.rhoUpdated;
+    const double inc = (s.prev_rho1 + s.prev_rho2) * s.rcr;                  // :1086
+    for (int q = 0; q < d.EPT; q++) {
+        const int i = blockIdx.x * (T * d.EPT) + q * T + threadIdx.x;
+        if (i >= d.n || !d.live[i]) continue;
+        const double x = d.x[i], z1 = d.z1[i], z2 = d.z2[i];
+        const double t = x + z1 / s.rho1;
+        const double y1 = t > 1 ? 1 : (t < 0 ? 0 : t);
+        double y2 = (x + z2 / s.rho2) - 0.5;
+        y2 = y2 * s.c1 / c2 + 0.5;
+        d.y1[i] = y1; d.y2[i] = y2;
+        double td = d.td[i];
+        if (refresh) { td += inc; d.td[i] = td; }
+        if (s.rhoUpdated || s.dinv_stale) d.dinv[i] = td != 0.0 ? 1.0 / td : 1.0;   // DiagonalPreconditioner::compute (:1098-1101)
+        d.rhs[i] = (s.rho1 * y1 + s.rho2 * y2) - ((d.b[i] + z1) + z2);         // :1091
+        d.x[i] = y1;                                                          // x_sol = y1 (:1104)
+    }
+    s.rhoUpdated = 0; s.dinv_stale = 0;
+    write_state(d, out, s);
+}
+
+__global__ void __launch_bounds__(T) seg_k_resid(SegDev d, int in, int out) {
+    __shared__ double red[2 * RED_MAXV * RED_MAXW];
+    int parity = 0;
+    SegState s = d.st[in];
+    if (s.halt) { write_state(d, out, s); return; }
+    double pb[3] = {0.0, 0.0, 0.0};
+    const double *x = d.x;
+    for (int q = 0; q < d.EPT; q++) {
+        const int i = blockIdx.x * (T * d.EPT) + q * T + threadIdx.x;
+        double c0 = 0.0, c1 = 0.0, c2 = 0.0;
+        if (i < d.n && d.live[i]) {
+            const double Mx = tm_row(d, i, [x](int c) { return x[c]; });
+            const double rhs = d.rhs[i];
+            const double r = rhs - Mx;                                        // :263
+            const double p = d.dinv[i] * r;                                   // :286
+            d.r[i] = r; d.p0[i] = p;
+            c0 = rhs * rhs; c1 = r * r; c2 = r * p;
+        }
+        pb[0] = pb[0] + c0; pb[1] = pb[1] + c1; pb[2] = pb[2] + c2;
+    }
+    store_partials<3>(d, PH_B, pb, red, parity);
+    s.pcg_k = 0; s.pcg_done = 0; s.phase = 2;
+    write_state(d, out, s);
+}
+
+// tmp = M p with the search-direction update of the previous PCG iteration folded in
+__global__ void __launch_bounds__(T) seg_k_matvec(SegDev d, int in, int out) {
+    __shared__ double red[2 * RED_MAXV * RED_MAXW];
+    int parity = 0;
+    SegState s = d.st[in];
+    if (s.halt || s.pcg_done || s.phase != 2) { write_state(d, out, s); return; }
+    double beta = 0.0;
+    bool first = s.pcg_k == 0, zero_x = false;
+    if (first) {
+        double b3[3];
+        final_sums<3>(d, PH_B, b3, red, parity);
+        s.rhsNorm2 = b3[0];
+        if (s.rhsNorm2 == 0) { s.pcg_done = 1; zero_x = true; }             // :265-271
+        else {
+            double thr = SEG_PCG_TOL * SEG_PCG_TOL * s.rhsNorm2;             // :274
+            if (thr < DBL_MIN) thr = DBL_MIN;
+            s.threshold = thr;
+            if (b3[1] < thr) s.pcg_done = 1;                                  // :277
+            s.absNew = b3[2];
+        }
+    } else {
+        double d2[2];
+        final_sums<2>(d, PH_D, d2, red, parity);
+        if (d2[0] < s.threshold || s.pcg_k >= SEG_PCG_MAXITERS) s.pcg_done = 1;   // :304-307
+        else { const double absOld = s.absNew; s.absNew = d2[1]; beta = s.absNew / absOld; }   // :311-313
+    }
+    if (s.pcg_done) {
+        if (zero_x)
+            for (int q = 0; q < d.EPT; q++) { const int i = blockIdx.x * (T * d.EPT) + q * T + threadIdx.x; if (i < d.n) d.x[i] = 0.0; }
+        write_state(d, out, s);
+        return;
+    }
+    // p buffers: iteration k reads p_old = buffer (k-1)&1 (k >= 1) and writes buffer k&1; k = 0 uses p0 as written by resid
+    const double *pold = ((s.pcg_k - 1) & 1) ? d.p1 : d.p0;
+    double *pnew = (s.pcg_k & 1) ? d.p1 : d.p0;
+    const double *zz = d.z;
+    double pc[1] = {0.0};
+    for (int q = 0; q < d.EPT; q++) {
+        const int i = blockIdx.x * (T * d.EPT) + q * T + threadIdx.x;
+        double c = 0.0;
+        if (i < d.n && d.live[i]) {
+            double Mp, pi;
+            if (first) {
+                pi = d.p0[i];
+                const double *p0 = d.p0;
+                Mp = tm_row(d, i, [p0](int c2) { return p0[c2]; });
+            } else {
+                pi = zz[i] + beta * pold[i];                                   // p = z + beta p (:314)
+                Mp = tm_row(d, i, [zz, pold, beta](int c2) { return zz[c2] + beta * pold[c2]; });
+                pnew[i] = pi;
+            }
+            d.tmp[i] = Mp;
+            c = pi * Mp;
+        }
+        pc[0] = pc[0] + c;
+    }
+    store_partials<1>(d, PH_C, pc, red, parity);
+    write_state(d, out, s);
+}
+
+__global__ void __launch_bounds__(T) seg_k_update(SegDev d, int in, int out) {
+    __shared__ double red[2 * RED_MAXV * RED_MAXW];
+    int parity = 0;
+    SegState s = d.st[in];
+    if (s.halt || s.pcg_done || s.phase != 2) { write_state(d, out, s); return; }
+    double c1[1];
+    final_sums<1>(d, PH_C, c1, red, parity);
+    const double alpha = s.absNew / c1[0];                                    // :295
+    const double *p = (s.pcg_k & 1) ? d.p1 : d.p0;
+    double pd2[2] = {0.0, 0.0};
+    for (int q = 0; q < d.EPT; q++) {
+        const int i = blockIdx.x * (T * d.EPT) + q * T + threadIdx.x;
+        double a = 0.0, b2 = 0.0;
+        if (i < d.n && d.live[i]) {
+            double x = d.x[i], r = d.r[i];
+            x += alpha * p[i];                                                // :297
+            r -= alpha * d.tmp[i];                                            // :299
+            const double z = d.dinv[i] * r;                                   // :309
+            d.x[i] = x; d.r[i] = r; d.z[i] = z;
+            a = r * r; b2 = r * z;
+        }
+        pd2[0] = pd2[0] + a; pd2[1] = pd2[1] + b2;
+    }
+    store_partials<2>(d, PH_D, pd2, red, parity);
+    s.pcg_k++;
+    write_state(d, out, s);
+}
+
+__global__ void __launch_bounds__(T) seg_k_post(SegDev d, int in, int out) {
+    __shared__ double red[2 * RED_MAXV * RED_MAXW];
+    int parity = 0;
+    SegState s = d.st[in];
+    if (s.halt || s.phase != 2) { write_state(d, out, s); return; }
+    if (!s.pcg_done) {                     // the exit test of the last update is still pending
+        double d2[2];
+        final_sums<2>(d, PH_D, d2, red, parity);
+        if (s.pcg_k >= 1 && (d2[0] < s.threshold || s.pcg_k >= SEG_PCG_MAXITERS)) s.pcg_done = 1;
+        else { s.halt = SEG_HALT_PCG_MORE; write_state(d, out, s); return; }
+    }
+    s.last_pcg = s.pcg_k; s.pcg_total += s.pcg_k; s.outer_total++;
+    const double g1 = s.gamma_val * s.rho1, g2 = s.gamma_val * s.rho2;
+    const double *x = d.x;
+    double e5[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, e2[2] = {0.0, 0.0};
+    double *xh = s.l2f ? d.xhist + (size_t)s.cc * d.n : nullptr;
+    for (int q = 0; q < d.EPT; q++) {
+        const int i = blockIdx.x * (T * d.EPT) + q * T + threadIdx.x;
+        double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0, v4 = 0.0, v5 = 0.0, v6 = 0.0;
+        if (i < d.n && d.live[i]) {
+            const double xi = x[i], y1 = d.y1[i], y2 = d.y2[i], bi = d.b[i];
+            d.z1[i] = d.z1[i] + g1 * (xi - y1);                               // :1119-1120
+            d.z2[i] = d.z2[i] + g2 * (xi - y2);
+            if (xh) xh[i] = xi;                                               // x_iters column (:1113-1116)
+            // A x and A round(x) in one pass over the row (compute_cost :568-572, A_ptr restricted to the live variables)
+            double t1 = 0, t2 = 0;
+            const int k1 = d.rowptr[i + 1];
+            for (int k = d.rowptr[i]; k < k1; k++) {
+                const int c = d.colidx[k];
+                const double xc = x[c], a = d.vals[k];
+                t1 += a * xc;
+                t2 += a * (xc >= 0.5 ? 1.0 : 0.0);                           // fixed variables hold x = 0
+            }
+            double Ax = 0.0; Ax += 1.0 * t1;
+            double Axb = 0.0; Axb += 1.0 * t2;
+            const double xb = xi >= 0.5 ? 1.0 : 0.0;
+            const double d1 = xi - y1, d2 = xi - y2;
+            v0 = xi * xi; v1 = d1 * d1; v2 = d2 * d2; v3 = xi * Ax; v4 = bi * xi; v5 = xb * Axb; v6 = bi * xb;
+        }
+        e5[0] = e5[0] + v0; e5[1] = e5[1] + v1; e5[2] = e5[2] + v2; e5[3] = e5[3] + v3; e5[4] = e5[4] + v4;
+        e2[0] = e2[0] + v5; e2[1] = e2[1] + v6;
+    }
+    block_sum<T, 5>(e5, red, parity);
+    block_sum<T, 2>(e2, red, parity);
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < 5; k++) part_ptr(d, PH_E, k)[blockIdx.x] = e5[k];
+        part_ptr(d, PH_E, 5)[blockIdx.x] = e2[0];
+        part_ptr(d, PH_E, 6)[blockIdx.x] = e2[1];
+    }
+    if (s.l2f) s.cc++;
+    s.have_prev = 1; s.phase = 0;
+    write_state(d, out, s);
+}
+
+__global__ void seg_k_pack(SegDev d, const int *live_idx, int rows, int ws, double *out) {
+    const long total = (long)rows * ws;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(e / ws), c = (int)(e % ws);
+        out[e] = d.xhist[(size_t)c * d.n + live_idx[r]];
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------
+hipError_t seg_launch_init(const SegDev &d, double c1, hipStream_t s) {
+    hipLaunchKernelGGL(seg_k_init, dim3(d.G), dim3(T), 0, s, d, c1);
+    return hipGetLastError();
+}
+
+// every launch flips the ping-pong index *parity (state read from st[*parity], written to st[*parity ^ 1])
+#define SEG_LAUNCH(kernel, grid, ...)                                                        \
+    do {                                                                                     \
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(T), 0, s, d, *parity, *parity ^ 1, ##__VA_ARGS__); \
+        *parity ^= 1;                                                                        \
+    } while (0)
+
+hipError_t seg_launch_set_window(const SegDev &d, int iter_start, int iter_end, int l2f, int *parity, hipStream_t s) {
+    hipLaunchKernelGGL(seg_k_set_window, dim3(1), dim3(1), 0, s, d, *parity, *parity ^ 1, iter_start, iter_end, l2f);
+    *parity ^= 1;
+    return hipGetLastError();
+}
+
+hipError_t seg_launch_fix(const SegDev &d, int n_live_new, double c1_new, int *parity, hipStream_t s) {
+    SEG_LAUNCH(seg_k_fix, d.G, n_live_new, c1_new);
+    return hipGetLastError();
+}
+
+hipError_t seg_enqueue_iterations(const SegDev &d, int iters, int kmax, int *parity, hipStream_t s) {
+    for (int it = 0; it < iters; it++) {
+        SEG_LAUNCH(seg_k_prep, d.G, 1);
+        SEG_LAUNCH(seg_k_yrhs, d.G);
+        SEG_LAUNCH(seg_k_resid, d.G);
+        for (int k = 0; k < kmax; k++) { SEG_LAUNCH(seg_k_matvec, d.G); SEG_LAUNCH(seg_k_update, d.G); }
+        SEG_LAUNCH(seg_k_post, d.G);
+    }
+    return hipGetLastError();
+}
+
+hipError_t seg_enqueue_pcg_more(const SegDev &d, int pairs, int *parity, hipStream_t s) {
+    hipLaunchKernelGGL(seg_k_resume, dim3(1), dim3(1), 0, s, d, *parity, *parity ^ 1);
+    *parity ^= 1;
+    for (int k = 0; k < pairs; k++) { SEG_LAUNCH(seg_k_matvec, d.G); SEG_LAUNCH(seg_k_update, d.G); }
+    SEG_LAUNCH(seg_k_post, d.G);
+    return hipGetLastError();
+}
+
+hipError_t seg_launch_copy(const SegDev &d, int *parity, hipStream_t s) {   // state copy only: flips the ping-pong parity
+    hipLaunchKernelGGL(seg_k_resume, dim3(1), dim3(1), 0, s, d, *parity, *parity ^ 1);
+    *parity ^= 1;
+    return hipGetLastError();
+}
+
+hipError_t seg_enqueue_finalize(const SegDev &d, int *parity, hipStream_t s) {
+    SEG_LAUNCH(seg_k_prep, d.G, 0);
+    return hipGetLastError();
+}
+
+hipError_t seg_launch_pack_xiters(const SegDev &d, const int *live_idx, int rows, int ws, double *out, hipStream_t s) {
+    hipLaunchKernelGGL(seg_k_pack, dim3(256), dim3(256), 0, s, d, live_idx, rows, ws, out);
+    return hipGetLastError();
+}

@@ -44,6 +44,13 @@ SYMBOLS = {
     "lpbox_cur_bin_obj": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
     "lpbox_check_infeasible_lpbox": (C.c_int, [C.c_void_p, C.c_int]),
     "lpbox_check_infeasible_l2f": (C.c_int, [C.c_void_p, C.c_int]),
+    "lpbox_set_problem_bqp": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _ip, _ip, _dp, _dp, C.c_double, C.c_int, C.c_int]),
+    "lpbox_seg_set_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "lpbox_seg_legacy": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "lpbox_seg_get_obj": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "lpbox_seg_get_shape": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "lpbox_seg_get_problem": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.POINTER(C.c_double)]),
     "lpbox_get_config": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "lpbox_get_layout": (C.c_int, [C.c_void_p, C.c_int, _ip]),
     "lpbox_get_row_split": (C.c_int, [C.c_void_p, C.c_int, _ip]),

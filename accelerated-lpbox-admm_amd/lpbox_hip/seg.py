@@ -1,0 +1,178 @@
+"""Host-side mirror of the reference's SEGMENTATION solver interface
+(Segmentation/Segmentation/cython/src/lpbox.pyx:8-53, "SEG pyx") on top of the C-ABI (include/lpbox_hip.h).
+
+The reference's init decodes `../data/<problem>.jpg` with OpenCV (SEGcpp:690-714).  OpenCV is not available, so the JPEG is
+decoded here with PIL straight to grayscale (libjpeg's Y channel, which is what cv::imread(path, 0) asks libjpeg for); the
+resize (cv::resize INTER_LINEAR) and the cost construction (SEGcpp:46-248) run in the C-ABI library.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import LpboxError, check  # noqa: F401
+from .lp import _as_int
+
+
+def load_gray(path):
+    """cv::imread(path, 0): 8-bit grayscale pixels, rows x cols."""
+    from PIL import Image
+    im = Image.open(path)
+    im.draft("L", im.size)
+    return np.ascontiguousarray(np.asarray(im.convert("L"), dtype=np.uint8))
+
+
+class PyLPboxADMMsolver:
+    """Same surface as the reference's segmentation `cdef class PyLPboxADMMsolver` (SEG pyx:8-53)."""
+
+    data_root = None      # directory holding <problem>.jpg; default: the reference's CWD-relative "../data" (SEGcpp:690)
+    result_root = None    # directory for save_img(); default "../result" (SEGcpp:691)
+    verbose = False
+
+    def __init__(self, print_info=0, numNodes=10000, problem=0):
+        self._L = _lib.load()
+        self.print_info = _as_int(print_info, "print_info")
+        self.numNodes = _as_int(numNodes, "numNodes")     # LP/SEG trainers pass 1e4 as a float (SEG/trainer.py:699)
+        self.problem = _as_int(problem, "problem")
+        h = self._L.lpbox_create(_lib.FLAVOUR_SEG, 1, self.print_info)
+        if not h:
+            check(-2, "lpbox_create")
+        self._h = C.c_void_p(h)
+        self._have_problem = False
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.lpbox_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- extensions: hand the image / the problem over in memory ----
+    def set_image(self, gray, numNodes=None):
+        gray = np.ascontiguousarray(gray, np.uint8)
+        if numNodes is None:
+            numNodes = self.numNodes
+        check(self._L.lpbox_seg_set_image(self._h, gray.ctypes.data_as(C.c_void_p), gray.shape[0], gray.shape[1], int(numNodes)),
+              "lpbox_seg_set_image")
+        self._have_problem = True
+
+    def set_problem(self, P):
+        check(self._L.lpbox_set_problem_bqp(self._h, int(P["n"]), len(P["colidx"]), np.ascontiguousarray(P["rowptr"], np.int32),
+                                            np.ascontiguousarray(P["colidx"], np.int32), np.ascontiguousarray(P["vals"], np.float64),
+                                            np.ascontiguousarray(P["b"], np.float64), float(P["c"]), int(P["rows"]), int(P["cols"])),
+              "lpbox_set_problem_bqp")
+        self._have_problem = True
+
+    def get_problem(self):
+        n, nnz, c = C.c_int(), C.c_int(), C.c_double()
+        check(self._L.lpbox_seg_get_problem(self._h, C.byref(n), C.byref(nnz), None, None, None, None, C.byref(c)), "lpbox_seg_get_problem")
+        rp, ci = np.zeros(n.value + 1, np.int32), np.zeros(nnz.value, np.int32)
+        va, b = np.zeros(nnz.value), np.zeros(n.value)
+        check(self._L.lpbox_seg_get_problem(self._h, C.byref(n), C.byref(nnz), rp.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(C.c_void_p),
+                                            va.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), C.byref(c)), "lpbox_seg_get_problem")
+        r, cc = C.c_int(), C.c_int()
+        check(self._L.lpbox_seg_get_shape(self._h, C.byref(r), C.byref(cc)), "lpbox_seg_get_shape")
+        return dict(n=n.value, rowptr=rp, colidx=ci, vals=va, b=b, c=c.value, rows=r.value, cols=cc.value)
+
+    # SEG pyx:17-18
+    def solve_init(self):
+        if not self._have_problem:
+            root = self.data_root or os.environ.get("LPBOX_SEG_DATA_ROOT") or "../data"
+            self.set_image(load_gray(os.path.join(root, f"{self.problem}.jpg")))
+        return check(self._L.lpbox_init(self._h), "lpbox_init")
+
+    # SEG pyx:20-21
+    def solve_iter(self):
+        e = C.c_int()
+        check(self._L.lpbox_seg_legacy(self._h, C.byref(e)), "lpbox_seg_legacy")
+        return e.value
+
+    # SEG pyx:23-24
+    def solve_iter_l2f(self, i, j, vec, num):
+        vec = np.ascontiguousarray(vec, np.float64).ravel()
+        num = _as_int(num, "num")
+        if num != 0 and vec.shape[0] < self.get_n():
+            raise ValueError("fix vector shorter than the number of live variables")
+        nums = (C.c_int * 1)(num)
+        rets = (C.c_int * 1)(0)
+        check(self._L.lpbox_iterate_l2f(self._h, _as_int(i, "i"), _as_int(j, "j"), vec.ctypes.data_as(C.c_void_p), vec.shape[0],
+                                        C.cast(nums, C.c_void_p), C.cast(rets, C.c_void_p)), "lpbox_iterate_l2f")
+        return rets[0]
+
+    # SEG pyx:26-33
+    def get_x_iters_2d(self, ws):
+        ws = _as_int(ws, "ws")
+        rows = check(self._L.lpbox_get_x_iters(self._h, 0, ws, None), "lpbox_get_x_iters")
+        out = np.zeros((rows, ws))
+        if rows and ws:
+            check(self._L.lpbox_get_x_iters(self._h, 0, ws, out.ctypes.data_as(C.c_void_p)), "lpbox_get_x_iters")
+        return out
+
+    # SEG pyx:35-39
+    def get_n(self):
+        return check(self._L.lpbox_get_n(self._h, 0), "lpbox_get_n")
+
+    def get_org_n(self):
+        return check(self._L.lpbox_get_org_n(self._h, 0), "lpbox_get_org_n")
+
+    # SEG pyx:41-42
+    def get_obj(self):
+        v = C.c_double()
+        check(self._L.lpbox_seg_get_obj(self._h, C.byref(v)), "lpbox_seg_get_obj")
+        return v.value
+
+    # SEG pyx:44-50
+    def get_x_sol(self):
+        out = np.zeros(self.get_org_n())
+        check(self._L.lpbox_get_x_sol(self._h, 0, out), "lpbox_get_x_sol")
+        return out.reshape(-1, 1)
+
+    # SEG pyx:52-53 (SEGcpp:812-837): white where x >= 0.5, reshaped column-major to the scaled image
+    def save_img(self, path=None):
+        from PIL import Image
+        r, c = C.c_int(), C.c_int()
+        check(self._L.lpbox_seg_get_shape(self._h, C.byref(r), C.byref(c)), "lpbox_seg_get_shape")
+        x = self.get_x_sol().ravel()
+        img = (x.reshape(c.value, r.value).T >= 0.5).astype(np.uint8) * 255      # Eigen::Map<DenseMatrix>(xx, rows, cols) is column-major
+        if path is None:
+            root = self.result_root or "../result"
+            os.makedirs(root, exist_ok=True)
+            path = os.path.join(root, f"output_{self.problem}.png")
+        Image.fromarray(img).save(path)
+        return path
+
+    # ---- extensions ----
+    def config(self):
+        t, e, g = C.c_int(), C.c_int(), C.c_int()
+        check(self._L.lpbox_get_config(self._h, C.byref(t), C.byref(e), C.byref(g)), "lpbox_get_config")
+        return dict(threads=t.value, elems_per_thread=e.value, groups=g.value)
+
+    def counters(self):
+        o, p = C.c_longlong(), C.c_longlong()
+        check(self._L.lpbox_get_counters(self._h, 0, C.byref(o), C.byref(p)), "lpbox_get_counters")
+        return o.value, p.value
+
+    def stop(self):
+        r, p = C.c_int(), C.c_int()
+        check(self._L.lpbox_get_stop(self._h, 0, C.byref(r), C.byref(p)), "lpbox_get_stop")
+        return r.value, p.value
+
+    def kernel_time(self, reset=False):
+        ms, n = C.c_double(), C.c_longlong()
+        check(self._L.lpbox_kernel_time(self._h, C.byref(ms), C.byref(n), int(bool(reset))), "lpbox_kernel_time")
+        return ms.value, n.value
+
+    def debug_vec(self, name):
+        out = np.zeros(self.get_org_n())
+        check(self._L.lpbox_debug_get_vec(self._h, 0, name.encode(), out, len(out)), "lpbox_debug_get_vec")
+        return out
+
+    def debug_scalar(self, name):
+        v = C.c_double()
+        check(self._L.lpbox_debug_get_scalar(self._h, 0, name.encode(), C.byref(v)), "lpbox_debug_get_scalar")
+        return v.value

@@ -90,6 +90,25 @@ int lpbox_cur_bin_obj(lpbox_t *h, int idx, double *out);      /* LP pxd:19 get_c
 int lpbox_check_infeasible_lpbox(lpbox_t *h, int idx);        /* LP pxd:20 (LPcpp:1577-1591): count, >= 0   */
 int lpbox_check_infeasible_l2f(lpbox_t *h, int idx);          /* LP pxd:21 (LPcpp:1593-1612): count, >= 0   */
 
+/* ---- segmentation flavour (handle created with LPBOX_FLAVOUR_SEG, batch 1) ---------------------
+ * The generic entry points above serve it too: lpbox_init = ADMM_bqp_unconstrained_init (SEG pxd:9, SEGcpp:658-810, after the
+ * problem has been set), lpbox_iterate_l2f = ADMM_bqp_unconstrained_l2f (SEG pxd:11, SEGcpp:917-1195, windows of <= 10
+ * iterations), lpbox_get_x_iters / _get_n / _get_org_n / _get_x_sol (SEG pxd:12-16). */
+/* What the reference's init holds after get_A_b_from_cost (SEGcpp:226-248, :755-756): A_ptr = A/2 row-major CSR (columns
+ * ascending, every row stores its diagonal), b, the constant c, and the image shape (for save_img). */
+int lpbox_set_problem_bqp(lpbox_t *h, int n, int nnz, const int *rowptr, const int *colidx, const double *vals,
+                          const double *b, double c, int rows, int cols);
+/* The image part of ADMM_bqp_unconstrained_init (SEGcpp:702-756): grayscale pixels (rows x cols, row-major, what
+ * cv::imread(path, 0) yields), scaled to ~num_nodes pixels (cv::resize INTER_LINEAR), costs per SEGcpp:46-248. */
+int lpbox_seg_set_image(lpbox_t *h, const unsigned char *gray, int rows, int cols, int num_nodes);
+/* SEG pxd:10 `int ADMM_bqp_unconstrained_legacy()` (SEGcpp:1200-1380): *energy = int(cur_obj + c). */
+int lpbox_seg_legacy(lpbox_t *h, int *energy);
+/* SEG pxd:15 `double get_final_obj()` (SEGcpp:868-893): energy of the assembled rounded solution on the ORIGINAL A, b, plus c. */
+int lpbox_seg_get_obj(lpbox_t *h, double *out);
+int lpbox_seg_get_shape(lpbox_t *h, int *rows, int *cols);   /* scaled_row, scaled_col (SEGcpp:716-717), for save_img */
+/* inspection: the problem the handle holds (pass NULL arrays to query n / nnz first) */
+int lpbox_seg_get_problem(lpbox_t *h, int *n, int *nnz, int *rowptr, int *colidx, double *vals, double *b, double *c);
+
 /* ---- extensions beyond the pxd (batching, measurement, inspection) ---------------------------- */
 /* Workgroup geometry picked for the batch: threads per instance and slots per thread (threads*slots storage positions;
  * the reduction tree depends on both). */

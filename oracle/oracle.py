@@ -233,3 +233,163 @@ def project_shifted_lp_ball(x):
     y = np.zeros_like(x)
     lib().lpo_project_shifted_lp_ball(len(x), x, y)
     return y
+
+
+# ------------------------------------------------------------------------------------------------
+# segmentation flavour (oracle/seg_oracle.c)
+# ------------------------------------------------------------------------------------------------
+_seg_bound = False
+
+
+def _seg_lib():
+    global _seg_bound
+    L = lib()
+    if _seg_bound:
+        return L
+    pi, pd_ = C.POINTER(C.c_int), C.POINTER(C.c_double)
+    L.sego_create.restype = C.c_void_p
+    L.sego_create.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.sego_destroy.argtypes = [C.c_void_p]
+    L.sego_set_order.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.sego_set_verbose.argtypes = [C.c_void_p, C.c_int]
+    L.sego_build_costs.argtypes = [C.c_int, C.c_int, _dp, pi, C.POINTER(pi), C.POINTER(pi), C.POINTER(pd_), C.POINTER(pd_), pd_]
+    L.sego_free_arrays.argtypes = [pi, pi, pd_, pd_]
+    L.sego_resize_linear_u8.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_double, pi, pi, C.c_void_p]
+    L.sego_set_problem.argtypes = [C.c_void_p, C.c_int, C.c_int, _ip, _ip, _dp, _dp, C.c_double, C.c_int, C.c_int]
+    L.sego_init.argtypes = [C.c_void_p]
+    L.sego_legacy.argtypes = [C.c_void_p]
+    L.sego_l2f.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, C.c_int]
+    for f in ("sego_get_n", "sego_get_org_n", "sego_get_x_iters_rows", "sego_last_stop", "sego_legacy_iter_plus1"):
+        getattr(L, f).argtypes = [C.c_void_p]
+    for f in ("sego_total_pcg", "sego_total_outer"):
+        getattr(L, f).argtypes = [C.c_void_p]
+        getattr(L, f).restype = C.c_long
+    L.sego_get_x_iters.argtypes = [C.c_void_p, C.c_int, _dp]
+    L.sego_get_x_sol.argtypes = [C.c_void_p, _dp]
+    L.sego_get_final_obj.argtypes = [C.c_void_p]
+    L.sego_get_final_obj.restype = C.c_double
+    L.sego_get_c.argtypes = [C.c_void_p]
+    L.sego_get_c.restype = C.c_double
+    L.sego_get_trace.argtypes = [C.c_void_p, _ip, C.c_int]
+    L.sego_get_vec.argtypes = [C.c_void_p, C.c_char_p, _dp, C.c_int]
+    L.sego_get_scalar.argtypes = [C.c_void_p, C.c_char_p]
+    L.sego_get_scalar.restype = C.c_double
+    _seg_bound = True
+    return L
+
+
+def seg_build_costs(img):
+    """SEGcpp:46-248: grayscale image (rows x cols, 0..255) -> dict(n, rowptr, colidx, vals, b, c, rows, cols)."""
+    L = _seg_lib()
+    img = np.ascontiguousarray(img, np.float64)
+    rows, cols = img.shape
+    n = C.c_int()
+    rp, ci = C.POINTER(C.c_int)(), C.POINTER(C.c_int)()
+    va, bb = C.POINTER(C.c_double)(), C.POINTER(C.c_double)()
+    c = C.c_double()
+    nnz = L.sego_build_costs(rows, cols, img, C.byref(n), C.byref(rp), C.byref(ci), C.byref(va), C.byref(bb), C.byref(c))
+    out = dict(n=n.value, rows=rows, cols=cols, c=c.value,
+               rowptr=np.ctypeslib.as_array(rp, (n.value + 1,)).copy(), colidx=np.ctypeslib.as_array(ci, (nnz,)).copy(),
+               vals=np.ctypeslib.as_array(va, (nnz,)).copy(), b=np.ctypeslib.as_array(bb, (n.value,)).copy())
+    L.sego_free_arrays(rp, ci, va, bb)
+    return out
+
+
+def seg_resize_u8(img_u8, scale):
+    L = _seg_lib()
+    img_u8 = np.ascontiguousarray(img_u8, np.uint8)
+    r, c = C.c_int(), C.c_int()
+    L.sego_resize_linear_u8(img_u8.shape[0], img_u8.shape[1], img_u8.ctypes.data_as(C.c_void_p), float(scale), C.byref(r), C.byref(c), None)
+    out = np.zeros((r.value, c.value), np.uint8)
+    L.sego_resize_linear_u8(img_u8.shape[0], img_u8.shape[1], img_u8.ctypes.data_as(C.c_void_p), float(scale), C.byref(r), C.byref(c),
+                            out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+class SegOracle:
+    """Mirror of Segmentation/Segmentation/cython/src/lpbox.pyx:8-53 on the CPU oracle."""
+
+    def __init__(self, print_info=0, numNodes=10000, problem=0, order=ORDER_EIGEN, T=256, chunk=512):
+        self.L = _seg_lib()
+        self.h = C.c_void_p(self.L.sego_create(int(print_info), int(numNodes), int(problem)))
+        self.L.sego_set_order(self.h, order, T, chunk)
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.sego_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def set_problem(self, P):
+        rc = self.L.sego_set_problem(self.h, P["n"], len(P["colidx"]), np.ascontiguousarray(P["rowptr"], np.int32),
+                                     np.ascontiguousarray(P["colidx"], np.int32), np.ascontiguousarray(P["vals"], np.float64),
+                                     np.ascontiguousarray(P["b"], np.float64), float(P["c"]), P["rows"], P["cols"])
+        if rc:
+            raise ValueError(rc)
+
+    def solve_init(self):
+        return self.L.sego_init(self.h)
+
+    def solve_iter(self):
+        return self.L.sego_legacy(self.h)
+
+    def solve_iter_l2f(self, i, j, vec, num):
+        rc = self.L.sego_l2f(self.h, int(i), int(j), np.ascontiguousarray(vec, np.float64), int(num))
+        if rc < 0:
+            raise RuntimeError(rc)
+        return rc
+
+    def get_n(self):
+        return self.L.sego_get_n(self.h)
+
+    def get_org_n(self):
+        return self.L.sego_get_org_n(self.h)
+
+    def get_x_iters_2d(self, ws):
+        rows = self.L.sego_get_x_iters_rows(self.h)
+        out = np.zeros((rows, ws))
+        if rows:
+            self.L.sego_get_x_iters(self.h, ws, out)
+        return out
+
+    def get_obj(self):
+        return self.L.sego_get_final_obj(self.h)
+
+    def get_x_sol(self):
+        out = np.zeros(self.get_org_n())
+        self.L.sego_get_x_sol(self.h, out)
+        return out.reshape(-1, 1)
+
+    def vec(self, name):
+        cap = self.get_org_n() + 8
+        out = np.zeros(cap)
+        k = self.L.sego_get_vec(self.h, name.encode(), out, cap)
+        if k < 0:
+            raise KeyError(name)
+        return out[:k].copy()
+
+    def scalar(self, name):
+        return self.L.sego_get_scalar(self.h, name.encode())
+
+    def pcg_trace(self):
+        out = np.zeros(20000, np.int32)
+        k = self.L.sego_get_trace(self.h, out, len(out))
+        return out[:k].copy()
+
+    @property
+    def total_pcg_iters(self):
+        return self.L.sego_total_pcg(self.h)
+
+    @property
+    def total_outer_iters(self):
+        return self.L.sego_total_outer(self.h)
+
+    @property
+    def last_stop(self):
+        return self.L.sego_last_stop(self.h)
+
+    @property
+    def legacy_iter_plus1(self):
+        return self.L.sego_legacy_iter_plus1(self.h)

@@ -1,0 +1,95 @@
+"""GPU parity tests of the SEGMENTATION flavour: HIP kernels (through the C-ABI) vs the CPU oracle in the kernels' reduction
+order.  Bar: bit-exact iterates / state / counters / energy."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, bits_equal, scripted_fix_vec
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def make_pair(num_nodes, image="0.jpg"):
+    from lpbox_hip.seg import PyLPboxADMMsolver, load_gray
+    gray = load_gray(os.path.join(GOLDEN, "seg", image))
+    g = PyLPboxADMMsolver(0, num_nodes, 0)
+    g.set_image(gray)
+    P = g.get_problem()
+    g.solve_init()
+    cfg = g.config()
+    o = O.SegOracle(0, num_nodes, 0, order=O.ORDER_GPU, T=cfg["threads"], chunk=cfg["threads"] * cfg["elems_per_thread"])
+    o.set_problem(P)
+    o.solve_init()
+    return g, o
+
+
+def compare_state(g, o, tag):
+    left = o.vec("left_idx").astype(int)
+    for name in ("x", "z1", "z2", "b"):
+        assert bits_equal(g.debug_vec(name)[left], o.vec(name)), f"{tag}: {name}"
+    for name in ("rho1", "gamma", "cur_obj", "std_obj", "cvg1", "cvg2", "obj_val", "best_bin_obj"):
+        assert g.debug_scalar(name) == o.scalar(name), f"{tag}: {name}"
+
+
+def test_l2f_windows_bit_exact():
+    g, o = make_pair(10000)
+    vec = np.zeros(g.get_org_n())
+    for w in range(4):
+        rg = g.solve_iter_l2f(w * 10, (w + 1) * 10, vec, 0)
+        ro = o.solve_iter_l2f(w * 10, (w + 1) * 10, vec, 0)
+        xg, xo = g.get_x_iters_2d(10), o.get_x_iters_2d(10)
+        if not bits_equal(xg, xo):
+            bad = np.where((xg != xo).any(axis=0))[0]
+            raise AssertionError(f"window {w}: first differing iteration {bad[0]}, max diff {np.abs(xg - xo)[:, bad[0]].max():.3e}")
+        assert rg == ro
+        assert g.counters() == (o.total_outer_iters, o.total_pcg_iters)
+        compare_state(g, o, f"window {w}")
+
+
+def test_legacy_full_solve_bit_exact():
+    g, o = make_pair(10000)
+    eg, eo = g.solve_iter(), o.solve_iter()
+    assert eg == eo
+    assert g.stop() == (o.last_stop, o.legacy_iter_plus1)
+    assert g.counters() == (o.total_outer_iters, o.total_pcg_iters)
+    assert np.array_equal(g.get_x_sol(), o.get_x_sol())
+    assert g.get_obj() == o.get_obj()
+    compare_state(g, o, "final")
+
+
+def test_early_fix_windows_bit_exact():
+    """SEG/trainer.py:699-745 with a scripted policy: windows of 10 iterations, fix what has settled."""
+    g, o = make_pair(10000, "7.jpg")
+    vec, num = np.zeros(g.get_org_n()), 0
+    fixed_any = False
+    for w in range(40):
+        rg = g.solve_iter_l2f(w * 10, (w + 1) * 10, vec, num)
+        ro = o.solve_iter_l2f(w * 10, (w + 1) * 10, vec, num)
+        assert rg == ro and g.get_n() == o.get_n(), f"window {w}"
+        if rg:
+            break
+        xg, xo = g.get_x_iters_2d(10), o.get_x_iters_2d(10)
+        assert bits_equal(xg, xo), f"window {w}"
+        compare_state(g, o, f"window {w}")
+        vec, num = scripted_fix_vec(xo, last=5)
+        if num <= 10:
+            num = 0
+        fixed_any |= num > 0
+    assert fixed_any
+    assert np.array_equal(g.get_x_sol(), o.get_x_sol())
+    assert g.get_obj() == o.get_obj()
+
+
+def test_full_resolution_image_windows_bit_exact():
+    """BASELINE config 3 size: 500 x 375 = 187 500 variables."""
+    from lpbox_hip.seg import load_gray
+    n = load_gray(os.path.join(GOLDEN, "seg", "0.jpg")).size
+    g, o = make_pair(n)
+    assert g.get_org_n() == 187500
+    vec = np.zeros(n)
+    for w in range(2):
+        assert g.solve_iter_l2f(w * 10, (w + 1) * 10, vec, 0) == o.solve_iter_l2f(w * 10, (w + 1) * 10, vec, 0)
+        assert bits_equal(g.get_x_iters_2d(10), o.get_x_iters_2d(10)), f"window {w}"
+    compare_state(g, o, "full-res")
