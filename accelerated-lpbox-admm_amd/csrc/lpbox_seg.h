@@ -47,12 +47,14 @@ struct SegState {
     int have_prev;       // an iteration's partE is waiting to be finalised
     int halt, stop, ret, l2f, cc;
     int pcg_total, outer_total, last_pcg, legacy_iter_p1;
+    int pcg_max;         // largest PCG iteration count since the host last reset it (drives the adaptive launch count)
     int dinv_stale;      // a fix rebuilt the diagonal while no rho update was pending (stale preconditioner = UB in the reference)
 };
 
 struct SegDev {
     int n, nnz, G, EPT;                    // G workgroups of SEG_T threads, EPT slots each
-    const int *rowptr, *colidx; const double *vals;    // A_ptr (row-major, ascending columns; SEGh:17)
+    // A_ptr (row-major, ascending columns; SEGh:17) in ELL form: slot k of row i at [k*n + i], rowlen[i] slots used
+    const int *ecol; const double *eval; const uint8_t *rowlen; int ell_w;
     double *x, *y1, *y2, *z1, *z2, *b, *rhs, *r, *z, *tmp, *dinv, *td, *p0, *p1;
     uint8_t *live;          // 1 live, 0 fixed (x = 0 there; the fixed value is kept in fixval)
     uint8_t *fixval;
@@ -70,5 +72,5 @@ hipError_t seg_launch_fix(const SegDev &d, int n_live_new, double c1_new, int *p
 hipError_t seg_enqueue_iterations(const SegDev &d, int iters, int kmax, int *parity, hipStream_t s);
 hipError_t seg_enqueue_pcg_more(const SegDev &d, int pairs, int *parity, hipStream_t s);   // resume a stalled PCG, then post
 hipError_t seg_enqueue_finalize(const SegDev &d, int *parity, hipStream_t s);              // finalise the last iteration only
-hipError_t seg_launch_copy(const SegDev &d, int *parity, hipStream_t s);                      // state copy (parity flip) only
+hipError_t seg_launch_copy(const SegDev &d, int reset_pcg_max, int *parity, hipStream_t s);   // state copy (parity flip), optionally pcg_max = 0
 hipError_t seg_launch_pack_xiters(const SegDev &d, const int *live_idx, int rows, int ws, double *out, hipStream_t s);

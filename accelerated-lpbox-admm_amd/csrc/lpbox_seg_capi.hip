@@ -25,6 +25,7 @@ struct Buf {
     void release() { if (p) (void)hipFree(p); p = nullptr; count = 0; }
 };
 constexpr int ITERS_PER_GRAPH = 4;
+constexpr int SEG_KMAX_LIMIT = 24;
 }  // namespace
 
 struct SegSolver {
@@ -39,10 +40,14 @@ struct SegSolver {
     int G = 0, EPT = 2, kmax = 10, parity = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr; int graph_parity = -1, graph_kmax = 0;
+    // one instantiated graph (ITERS_PER_GRAPH iterations) per launch count kmax and start parity
+    hipGraph_t graph[SEG_KMAX_LIMIT + 1][2] = {}; hipGraphExec_t gexec[SEG_KMAX_LIMIT + 1][2] = {};
+    bool adaptive = true;
     double kernel_ms = 0.0; long long launches = 0;
-    Buf<int> d_rowptr, d_colidx, d_left;
-    Buf<double> d_vals, x, y1, y2, z1, z2, b, rhs, r, z, tmp, dinv, td, p0, p1, part, xhist, xi_out;
+    Buf<int> d_ecol, d_left;
+    Buf<uint8_t> d_rowlen;
+    int ell_w = 0;
+    Buf<double> d_eval, x, y1, y2, z1, z2, b, rhs, r, z, tmp, dinv, td, p0, p1, part, xhist, xi_out;
     Buf<uint8_t> live, fixval, newfix;
     Buf<SegState> st;
     int ws_cap = 0, last_ws = 0;
@@ -51,7 +56,7 @@ struct SegSolver {
     SegDev dev() const {
         SegDev d;
         d.n = n; d.nnz = nnz; d.G = G; d.EPT = EPT;
-        d.rowptr = d_rowptr.p; d.colidx = d_colidx.p; d.vals = d_vals.p;
+        d.ecol = d_ecol.p; d.eval = d_eval.p; d.rowlen = d_rowlen.p; d.ell_w = ell_w;
         d.x = x.p; d.y1 = y1.p; d.y2 = y2.p; d.z1 = z1.p; d.z2 = z2.p; d.b = b.p; d.rhs = rhs.p; d.r = r.p; d.z = z.p;
         d.tmp = tmp.p; d.dinv = dinv.p; d.td = td.p; d.p0 = p0.p; d.p1 = p1.p; d.live = live.p; d.fixval = fixval.p;
         d.newfix = newfix.p; d.part = part.p; d.xhist = xhist.p; d.ws_cap = ws_cap; d.st = st.p;
@@ -171,14 +176,29 @@ int upload(SegSolver *s) {
     if (s->G > 2 * SEG_T) return lpbox_fail(LPBOX_E_UNSUPPORTED, "n = %d is beyond the two-level reduction of the segmentation kernels", n);
     if (!s->stream) HIPCHK(hipStreamCreate(&s->stream));
     if (!s->ev0) { HIPCHK(hipEventCreate(&s->ev0)); HIPCHK(hipEventCreate(&s->ev1)); }
-    HIPCHK(s->d_rowptr.alloc((size_t)n + 1)); HIPCHK(s->d_colidx.alloc(s->nnz)); HIPCHK(s->d_vals.alloc(s->nnz)); HIPCHK(s->d_left.alloc(n));
+    int w = 0;
+    for (int i = 0; i < n; i++) w = std::max(w, s->rowptr[i + 1] - s->rowptr[i]);
+    if (w > 255) return lpbox_fail(LPBOX_E_UNSUPPORTED, "a row of A stores %d entries; the ELL layout of the segmentation kernels holds at most 255", w);
+    s->ell_w = w;
+    HIPCHK(s->d_ecol.alloc((size_t)w * n)); HIPCHK(s->d_eval.alloc((size_t)w * n)); HIPCHK(s->d_rowlen.alloc(n)); HIPCHK(s->d_left.alloc(n));
     for (Buf<double> *bp : {&s->x, &s->y1, &s->y2, &s->z1, &s->z2, &s->b, &s->rhs, &s->r, &s->z, &s->tmp, &s->dinv, &s->td, &s->p0, &s->p1})
         HIPCHK(bp->alloc(n));
     HIPCHK(s->live.alloc(n)); HIPCHK(s->fixval.alloc(n)); HIPCHK(s->newfix.alloc(n));
     HIPCHK(s->part.alloc((size_t)5 * SEG_NPART * s->G)); HIPCHK(s->st.alloc(2));
-    HIPCHK(hipMemcpy(s->d_rowptr.p, s->rowptr.data(), sizeof(int) * ((size_t)n + 1), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(s->d_colidx.p, s->colidx.data(), sizeof(int) * (size_t)s->nnz, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(s->d_vals.p, s->vals.data(), sizeof(double) * (size_t)s->nnz, hipMemcpyHostToDevice));
+    {
+        std::vector<int> ecol((size_t)w * n); std::vector<double> eval((size_t)w * n, 0.0); std::vector<uint8_t> rl(n);
+        for (int i = 0; i < n; i++) {
+            const int len = s->rowptr[i + 1] - s->rowptr[i];
+            rl[i] = (uint8_t)len;
+            for (int k = 0; k < w; k++) {
+                ecol[(size_t)k * n + i] = k < len ? s->colidx[s->rowptr[i] + k] : i;
+                if (k < len) eval[(size_t)k * n + i] = s->vals[s->rowptr[i] + k];
+            }
+        }
+        HIPCHK(hipMemcpy(s->d_ecol.p, ecol.data(), sizeof(int) * ecol.size(), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(s->d_eval.p, eval.data(), sizeof(double) * eval.size(), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(s->d_rowlen.p, rl.data(), rl.size(), hipMemcpyHostToDevice));
+    }
     HIPCHK(hipMemset(s->part.p, 0, sizeof(double) * (size_t)5 * SEG_NPART * s->G));
     HIPCHK(hipMemset(s->newfix.p, 0, n));
     s->uploaded = true;
@@ -193,40 +213,50 @@ int read_state(SegSolver *s) {
 
 // one hipGraph = ITERS_PER_GRAPH outer iterations (an even number of launches, so the state ping-pong parity is preserved)
 int ensure_graph(SegSolver *s) {
-    if (s->gexec && s->graph_parity == s->parity && s->graph_kmax == s->kmax) return LPBOX_OK;
-    if (s->gexec) { (void)hipGraphExecDestroy(s->gexec); s->gexec = nullptr; }
-    if (s->graph) { (void)hipGraphDestroy(s->graph); s->graph = nullptr; }
+    if (s->gexec[s->kmax][s->parity]) return LPBOX_OK;
     int par = s->parity;
     HIPCHK(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
     hipError_t e = seg_enqueue_iterations(s->dev(), ITERS_PER_GRAPH, s->kmax, &par, s->stream);
-    hipError_t e2 = hipStreamEndCapture(s->stream, &s->graph);
+    hipError_t e2 = hipStreamEndCapture(s->stream, &s->graph[s->kmax][s->parity]);
     if (e != hipSuccess || e2 != hipSuccess) return lpbox_fail(LPBOX_E_HIP, "graph capture failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
-    HIPCHK(hipGraphInstantiate(&s->gexec, s->graph, nullptr, nullptr, 0));
-    s->graph_parity = s->parity; s->graph_kmax = s->kmax;
+    HIPCHK(hipGraphInstantiate(&s->gexec[s->kmax][s->parity], s->graph[s->kmax][s->parity], nullptr, nullptr, 0));
     return LPBOX_OK;
 }
 
-// run iterations [iter_start, iter_end) (the window must already be set); returns when stopped / window done / all fixed
+void drop_graphs(SegSolver *s) {
+    for (int k = 0; k <= SEG_KMAX_LIMIT; k++) for (int p = 0; p < 2; p++) {
+        if (s->gexec[k][p]) { (void)hipGraphExecDestroy(s->gexec[k][p]); s->gexec[k][p] = nullptr; }
+        if (s->graph[k][p]) { (void)hipGraphDestroy(s->graph[k][p]); s->graph[k][p] = nullptr; }
+    }
+}
+
+// run iterations up to iter_end (the window must already be set); returns when stopped / window done / all fixed.
+// Each batch enqueues kmax (matvec, update) pairs per outer iteration; kernels fall through once the PCG has converged, so
+// kmax only has to cover the iteration counts seen recently (pcg_max of the previous batch + 2); a batch that runs out of
+// pairs halts itself (SEG_HALT_PCG_MORE) and is resumed here.
 int run_window(SegSolver *s, int iter_end) {
+    static const bool nograph = getenv("LPBOX_SEG_NOGRAPH") != nullptr;   // eager launches (profilers that dislike graphs)
     HIPCHK(hipEventRecord(s->ev0, s->stream));
-    const int per_launch = 4 + 2 * s->kmax;
     for (;;) {
         int rc = read_state(s);
         if (rc) return rc;
         if (s->hst.halt == SEG_HALT_PCG_MORE) {
             HIPCHK(seg_enqueue_pcg_more(s->dev(), 16, &s->parity, s->stream));
             s->launches += 34;
+            if (s->adaptive) s->kmax = std::min(SEG_KMAX_LIMIT, std::max(s->kmax, s->hst.pcg_k + 4));
             continue;
         }
         if (s->hst.halt != SEG_HALT_NONE) break;
         const int remaining = iter_end - s->hst.iter;
         if (remaining <= 0 && !s->hst.have_prev) break;
+        if (s->adaptive && s->hst.outer_total > 0) s->kmax = std::min(SEG_KMAX_LIMIT, std::max(2, s->hst.pcg_max + 2));
+        HIPCHK(seg_launch_copy(s->dev(), 1, &s->parity, s->stream));       // pcg_max = 0 for the coming batch
+        s->launches++;
+        const int per_launch = 4 + 2 * s->kmax;
         int batch = std::min(std::max(remaining, 0), 32);
-        if (s->gexec && s->graph_parity != s->parity && s->graph_kmax == s->kmax) { HIPCHK(seg_launch_copy(s->dev(), &s->parity, s->stream)); s->launches++; }
-        rc = ensure_graph(s);
-        if (rc) return rc;
-        while (batch >= ITERS_PER_GRAPH) {
-            HIPCHK(hipGraphLaunch(s->gexec, s->stream));
+        if (!nograph) { rc = ensure_graph(s); if (rc) return rc; }
+        while (!nograph && batch >= ITERS_PER_GRAPH) {
+            HIPCHK(hipGraphLaunch(s->gexec[s->kmax][s->parity], s->stream));
             batch -= ITERS_PER_GRAPH; s->launches += (long long)ITERS_PER_GRAPH * per_launch;
         }
         if (batch > 0) { HIPCHK(seg_enqueue_iterations(s->dev(), batch, s->kmax, &s->parity, s->stream)); s->launches += (long long)batch * per_launch; }
@@ -247,7 +277,7 @@ SegSolver *segc_create(int print_info, int device) {
     SegSolver *s = new SegSolver();
     s->print_info = print_info; s->device = device;
     memset(&s->hst, 0, sizeof(s->hst));
-    if (const char *e = getenv("LPBOX_SEG_KMAX")) { int v = atoi(e); if (v >= 1 && v <= 64) s->kmax = v; }
+    if (const char *e = getenv("LPBOX_SEG_KMAX")) { int v = atoi(e); if (v >= 1 && v <= SEG_KMAX_LIMIT) { s->kmax = v; s->adaptive = false; } }
     return s;
 }
 
@@ -255,9 +285,8 @@ void segc_destroy(SegSolver *s) {
     if (!s) return;
     if (s->uploaded) (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
-    if (s->gexec) (void)hipGraphExecDestroy(s->gexec);
-    if (s->graph) (void)hipGraphDestroy(s->graph);
-    s->d_rowptr.release(); s->d_colidx.release(); s->d_left.release(); s->d_vals.release();
+    drop_graphs(s);
+    s->d_ecol.release(); s->d_rowlen.release(); s->d_left.release(); s->d_eval.release();
     for (Buf<double> *bp : {&s->x, &s->y1, &s->y2, &s->z1, &s->z2, &s->b, &s->rhs, &s->r, &s->z, &s->tmp, &s->dinv, &s->td, &s->p0, &s->p1,
                             &s->part, &s->xhist, &s->xi_out})
         bp->release();
@@ -310,7 +339,7 @@ int segc_init(SegSolver *s) {
     HIPCHK(hipMemcpyAsync(s->b.p, s->orgb.data(), sizeof(double) * (size_t)s->n, hipMemcpyHostToDevice, s->stream));
     s->left_idx.resize(s->n);
     for (int i = 0; i < s->n; i++) s->left_idx[i] = i;
-    s->xi_valid = false; s->parity = 0; s->graph_parity = -1;
+    s->xi_valid = false; s->parity = 0;
     HIPCHK(seg_launch_init(s->dev(), std::pow((double)s->n, 1.0 / 2), s->stream));    // pow(n, 1/p), p = 2 (SEGcpp:557,670)
     rc = read_state(s);
     if (rc) return rc;
@@ -359,7 +388,7 @@ int segc_l2f(SegSolver *s, int iter_start, int iter_end, const double *vec, int 
     s->xi_rows = n_live - num; s->xi_left_idx = s->left_idx;
     if (ws > 0 && (!s->xhist.p || s->ws_cap < ws)) {
         HIPCHK(hipStreamSynchronize(s->stream));
-        HIPCHK(s->xhist.alloc((size_t)SEG_XITERS_COLS * s->n)); s->ws_cap = SEG_XITERS_COLS; s->graph_parity = -1;
+        HIPCHK(s->xhist.alloc((size_t)SEG_XITERS_COLS * s->n)); s->ws_cap = SEG_XITERS_COLS; drop_graphs(s);
     }
     if (ws > 0) HIPCHK(hipMemsetAsync(s->xhist.p, 0, sizeof(double) * (size_t)s->ws_cap * s->n, s->stream));
     if (!s->left_idx.empty()) HIPCHK(hipMemcpyAsync(s->d_left.p, s->left_idx.data(), sizeof(int) * s->left_idx.size(), hipMemcpyHostToDevice, s->stream));

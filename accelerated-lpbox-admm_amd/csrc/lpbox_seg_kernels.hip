@@ -49,19 +49,25 @@ __device__ __forceinline__ void store_partials(const SegDev &d, int phase, doubl
     }
 }
 
-__device__ __forceinline__ void write_state(const SegDev &d, int out, const SegState &s) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) d.st[out] = s;
+#define LEADER (blockIdx.x == 0 && threadIdx.x == 0)
+
+// The control state is read field by field (uniform scalar loads); only thread 0 of workgroup 0 copies it forward and
+// edits it.  (A per-thread copy of the whole struct would live in scratch memory and cost ~15 us of dispatch per launch.)
+__device__ __forceinline__ void forward_state(const SegDev &d, int in, int out) {
+    if (LEADER) d.st[out] = d.st[in];
 }
 
-// (2A + (rho1+rho2) I) row i times a gathered vector: diagonal entry = td[i], off-diagonal = 2*A_ik (SEGcpp:784-786)
+// (2A + (rho1+rho2) I) row i times a gathered vector: diagonal entry = td[i], off-diagonal = 2*A_ik (SEGcpp:784-786).
+// The matrix is held in ELL form (slot k of row i at [k*n + i], ascending columns): consecutive lanes = consecutive rows
+// read consecutive addresses, and the 7-diagonal structure makes the gathers of v coalesced as well.
 template <typename GET>
 __device__ __forceinline__ double tm_row(const SegDev &d, int i, GET get) {
     double tmp = 0;
-    const int k1 = d.rowptr[i + 1];
+    const int len = d.rowlen[i];
     const double tdi = d.td[i];
-    for (int k = d.rowptr[i]; k < k1; k++) {
-        const int c = d.colidx[k];
-        const double val = (c == i) ? tdi : 2 * d.vals[k];
+    for (int k = 0; k < len; k++) {
+        const int c = d.ecol[(size_t)k * d.n + i];
+        const double val = (c == i) ? tdi : 2 * d.eval[(size_t)k * d.n + i];
         tmp += val * get(c);
     }
     double res = 0.0;
@@ -77,39 +83,39 @@ __global__ void __launch_bounds__(T) seg_k_init(SegDev d, double c1) {      // A
         d.x[i] = 0.0; d.y1[i] = 0.0; d.y2[i] = 0.0; d.z1[i] = 0.0; d.z2[i] = 0.0;   // :762-777
         d.live[i] = 1; d.fixval[i] = 0;
         double aii = 0.0;
-        for (int k = d.rowptr[i]; k < d.rowptr[i + 1]; k++) if (d.colidx[k] == i) aii = d.vals[k];
+        for (int k = 0; k < d.rowlen[i]; k++) if (d.ecol[(size_t)k * d.n + i] == i) aii = d.eval[(size_t)k * d.n + i];
         double t = 2 * aii;
         t += SEG_RHO0 + SEG_RHO0;                                           // temp_mat.diagonal() += rho1 + rho2 (:785)
         d.td[i] = t;
         d.dinv[i] = 1.0; d.r[i] = 0.0; d.z[i] = 0.0; d.tmp[i] = 0.0; d.p0[i] = 0.0; d.p1[i] = 0.0; d.rhs[i] = 0.0;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        SegState s;
-        memset(&s, 0, sizeof(s));
-        s.rho1 = s.rho2 = s.prev_rho1 = s.prev_rho2 = SEG_RHO0;
-        s.gamma_val = SEG_GAMMA0; s.std_obj = 1.0; s.rhoUpdated = 1;
-        s.best_bin_obj = 0.0 + 0.0;                                         // compute_cost(x = 0) (:792)
-        s.n_live = d.n; s.c1 = c1;
-        d.st[0] = s; d.st[1] = s;
+    if (LEADER) {
+        SegState *s = d.st;
+        memset(s, 0, sizeof(SegState));
+        s->rho1 = s->rho2 = s->prev_rho1 = s->prev_rho2 = SEG_RHO0;
+        s->gamma_val = SEG_GAMMA0; s->std_obj = 1.0; s->rhoUpdated = 1;
+        s->best_bin_obj = 0.0 + 0.0;                                        // compute_cost(x = 0) (:792)
+        s->n_live = d.n; s->c1 = c1;
+        d.st[1] = d.st[0];
     }
 }
 
 __global__ void seg_k_set_window(SegDev d, int in, int out, int iter_start, int iter_end, int l2f) {
-    SegState s = d.st[in];
-    s.iter = iter_start; s.iter_end = iter_end; s.l2f = l2f; s.cc = 0; s.ret = 0; s.stop = SEG_STOP_NONE;
-    if (s.halt != SEG_HALT_ALLFIXED) s.halt = SEG_HALT_NONE;
-    d.st[out] = s;
+    d.st[out] = d.st[in];
+    SegState *s = d.st + out;
+    s->iter = iter_start; s->iter_end = iter_end; s->l2f = l2f; s->cc = 0; s->ret = 0; s->stop = SEG_STOP_NONE;
+    if (s->halt != SEG_HALT_ALLFIXED) s->halt = SEG_HALT_NONE;
 }
 
-__global__ void seg_k_resume(SegDev d, int in, int out) {
-    SegState s = d.st[in];
-    if (s.halt == SEG_HALT_PCG_MORE) s.halt = SEG_HALT_NONE;
-    d.st[out] = s;
+__global__ void seg_k_resume(SegDev d, int in, int out, int reset_pcg_max) {
+    d.st[out] = d.st[in];
+    if (d.st[out].halt == SEG_HALT_PCG_MORE) d.st[out].halt = SEG_HALT_NONE;
+    if (reset_pcg_max) d.st[out].pcg_max = 0;
 }
 
 // early fixing as a mask (SEGcpp:927-1062): fixed variables leave the problem, b := 2*Mb*x2 + b1, temp_mat rebuilt
 __global__ void __launch_bounds__(T) seg_k_fix(SegDev d, int in, int out, int n_live_new, double c1_new) {
-    SegState s = d.st[in];
+    const double rho12 = d.st[in].rho1 + d.st[in].rho2;
     for (int q = 0; q < d.EPT; q++) {
         const int i = blockIdx.x * (T * d.EPT) + q * T + threadIdx.x;
         if (i >= d.n) continue;
@@ -118,131 +124,148 @@ __global__ void __launch_bounds__(T) seg_k_fix(SegDev d, int in, int out, int n_
         if (!d.live[i]) continue;
         if (n_live_new == 0) continue;
         double tmp = 0, aii = 0.0;
-        for (int k = d.rowptr[i]; k < d.rowptr[i + 1]; k++) {
-            const int c = d.colidx[k];
-            if (c == i) aii = d.vals[k];
+        for (int k = 0; k < d.rowlen[i]; k++) {
+            const int c = d.ecol[(size_t)k * d.n + i];
+            const double a = d.eval[(size_t)k * d.n + i];
+            if (c == i) aii = a;
             const int nfc = d.newfix[c];
-            if (nfc) tmp += d.vals[k] * (nfc == 2 ? 1.0 : 0.0);            // Mb * x2, ascending column (:1051)
+            if (nfc) tmp += a * (nfc == 2 ? 1.0 : 0.0);                      // Mb * x2, ascending column (:1051)
         }
         double res = 0.0;
         res += 1.0 * tmp;
         d.b[i] = 2 * res + d.b[i];                                          // :1052
         double t = 2 * aii;
-        t += s.rho1 + s.rho2;                                               // :1054-1057
+        t += rho12;                                                         // :1054-1057
         d.td[i] = t;
     }
-    if (n_live_new == 0) { s.ret = 1; s.stop = SEG_STOP_ALLFIXED; s.halt = SEG_HALT_ALLFIXED; s.n_live = 0; }   // :1028-1032
-    else { s.n_live = n_live_new; s.c1 = c1_new; s.dinv_stale = 1; }
-    write_state(d, out, s);
+    if (LEADER) {
+        d.st[out] = d.st[in];
+        SegState *s = d.st + out;
+        if (n_live_new == 0) { s->ret = 1; s->stop = SEG_STOP_ALLFIXED; s->halt = SEG_HALT_ALLFIXED; s->n_live = 0; }   // :1028-1032
+        else { s->n_live = n_live_new; s->c1 = c1_new; s->dinv_stale = 1; }
+    }
 }
 
-// prep: finalise the previous iteration, then start the next one
+// prep: finalise the previous iteration (workgroup 0 only), then start the next one
 __global__ void __launch_bounds__(T) seg_k_prep(SegDev d, int in, int out, int do_prep) {
     __shared__ double red[2 * RED_MAXV * RED_MAXW];
     int parity = 0;
-    SegState s = d.st[in];
-    if (!s.halt && s.have_prev) {
-        double e[5];
-        final_sums<5>(d, PH_E, e, red, parity);                              // x.x, |x-y1|^2, |x-y2|^2, x.Ax, b.x
-        double e2[2];
-        {
+    const SegState *si = d.st + in;
+    const int halt0 = si->halt, have_prev = si->have_prev, it = si->iter, iter_end = si->iter_end;
+    double rho2 = si->rho2;
+    // what every workgroup can decide without the sums: the rho the next iteration will use, and whether a next one exists
+    const bool fin = !halt0 && have_prev;
+    if (fin && (it + 1) % SEG_RHO_STEP == 0) rho2 = SEG_LEARNING_FACT * rho2;
+    const int next_iter = fin ? it + 1 : it;
+    const bool will_prep = do_prep && !halt0 && next_iter < iter_end;       // (a stop detected below only wastes this launch's partials)
+    if (blockIdx.x == 0) {
+        double e[5] = {0, 0, 0, 0, 0}, e2[2] = {0, 0};
+        if (fin) {                                                          // uniform over the workgroup
+            final_sums<5>(d, PH_E, e, red, parity);                          // x.x, |x-y1|^2, |x-y2|^2, x.Ax, b.x
             const double *p5 = part_ptr(d, PH_E, 5), *p6 = part_ptr(d, PH_E, 6);
             double a = 0.0, b2 = 0.0;
             for (int q = threadIdx.x; q < d.G; q += T) { a = a + p5[q]; b2 = b2 + p6[q]; }
             e2[0] = a; e2[1] = b2;
             block_sum<T, 2>(e2, red, parity);                                // xb.A xb, b.xb
         }
-        s.have_prev = 0;
-        const int it = s.iter;
-        const double xn = sqrt(e[0]);
-        const double t0 = xn < 2.2204e-16 ? 2.2204e-16 : xn;
-        s.cvg1 = sqrt(e[1]) / t0; s.cvg2 = sqrt(e[2]) / t0;
-        const double bin_cost = e2[0] + e2[1];                               // compute_cost(round(x)) (:1167 / :1372)
-        bool stopped = false;
-        if (s.cvg1 <= SEG_STOP_THRESHOLD && s.cvg2 <= SEG_STOP_THRESHOLD) {  // :1127 / :1282
-            if (s.l2f) s.ret = 1;
-            s.stop = SEG_STOP_XYY; stopped = true;
-        } else {
-            if ((it + 1) % SEG_RHO_STEP == 0) {                              // :1137-1145
-                s.prev_rho1 = s.rho1; s.prev_rho2 = s.rho2;
-                s.rho1 = SEG_LEARNING_FACT * s.rho1; s.rho2 = SEG_LEARNING_FACT * s.rho2;
-                const double g = s.gamma_val * SEG_GAMMA_FACTOR;
-                s.gamma_val = g < 1.0 ? 1.0 : g;
-                s.rhoUpdated = 1; s.rcr = SEG_LEARNING_FACT - 1.0;
+        if (threadIdx.x == 0) {
+            d.st[out] = *si;
+            SegState *s = d.st + out;
+            if (fin) {
+                s->have_prev = 0;
+                const double xn = sqrt(e[0]);
+                const double t0 = xn < 2.2204e-16 ? 2.2204e-16 : xn;
+                s->cvg1 = sqrt(e[1]) / t0; s->cvg2 = sqrt(e[2]) / t0;
+                const double bin_cost = e2[0] + e2[1];                       // compute_cost(round(x)) (:1167 / :1372)
+                bool stopped = false;
+                if (s->cvg1 <= SEG_STOP_THRESHOLD && s->cvg2 <= SEG_STOP_THRESHOLD) {   // :1127 / :1282
+                    if (s->l2f) s->ret = 1;
+                    s->stop = SEG_STOP_XYY; stopped = true;
+                } else {
+                    if ((it + 1) % SEG_RHO_STEP == 0) {                      // :1137-1145
+                        s->prev_rho1 = s->rho1; s->prev_rho2 = s->rho2;
+                        s->rho1 = SEG_LEARNING_FACT * s->rho1; s->rho2 = SEG_LEARNING_FACT * s->rho2;
+                        const double g = s->gamma_val * SEG_GAMMA_FACTOR;
+                        s->gamma_val = g < 1.0 ? 1.0 : g;
+                        s->rhoUpdated = 1; s->rcr = SEG_LEARNING_FACT - 1.0;
+                    }
+                    s->obj_val = e[3] + e[4];                                // compute_cost(x) (:1148)
+                    int hn = s->hist_n;
+                    if (hn < SEG_HIST) s->hist[hn] = s->obj_val;
+                    else { for (int k = 0; k < SEG_HIST - 1; k++) s->hist[k] = s->hist[k + 1]; s->hist[SEG_HIST - 1] = s->obj_val; }
+                    if (hn < 0x3fffffff) hn++;
+                    s->hist_n = hn;
+                    if (hn >= SEG_HIST) {
+                        double mean = 0;
+                        for (int k = 0; k < SEG_HIST; k++) mean += s->hist[k];
+                        mean /= (double)SEG_HIST;
+                        double dev = 0;
+                        for (int k = 0; k < SEG_HIST; k++) dev += (s->hist[k] - mean) * (s->hist[k] - mean);
+                        dev /= (double)(SEG_HIST - 1);
+                        const double sd = dev == 0 ? 0.0 : sqrt(dev);
+                        s->std_obj = sd / fabs(s->hist[SEG_HIST - 1]);
+                    }
+                    if (s->std_obj <= SEG_STD_THRESHOLD) { if (s->l2f) s->ret = 1; s->stop = SEG_STOP_OBJSTD; stopped = true; }
+                    else {
+                        s->cur_obj = bin_cost;
+                        if (s->best_bin_obj >= s->cur_obj) s->best_bin_obj = s->cur_obj;
+                    }
+                }
+                if (stopped) {
+                    s->halt = SEG_HALT_STOP;
+                    if (!s->l2f) { s->cur_obj = bin_cost; s->legacy_iter_p1 = it + 1; }   // legacy epilogue (:1371-1376)
+                } else s->iter = it + 1;
             }
-            s.obj_val = e[3] + e[4];                                         // compute_cost(x) (:1148)
-            if (s.hist_n < SEG_HIST) s.hist[s.hist_n] = s.obj_val;
-            else { for (int k = 0; k < SEG_HIST - 1; k++) s.hist[k] = s.hist[k + 1]; s.hist[SEG_HIST - 1] = s.obj_val; }
-            if (s.hist_n < 0x3fffffff) s.hist_n++;
-            if (s.hist_n >= SEG_HIST) {
-                double mean = 0;
-                for (int k = 0; k < SEG_HIST; k++) mean += s.hist[k];
-                mean /= (double)SEG_HIST;
-                double dev = 0;
-                for (int k = 0; k < SEG_HIST; k++) dev += (s.hist[k] - mean) * (s.hist[k] - mean);
-                dev /= (double)(SEG_HIST - 1);
-                const double sd = dev == 0 ? 0.0 : sqrt(dev);
-                s.std_obj = sd / fabs(s.hist[SEG_HIST - 1]);
-            }
-            if (s.std_obj <= SEG_STD_THRESHOLD) { if (s.l2f) s.ret = 1; s.stop = SEG_STOP_OBJSTD; stopped = true; }
-            else {
-                s.cur_obj = bin_cost;
-                if (s.best_bin_obj >= s.cur_obj) s.best_bin_obj = s.cur_obj;
-            }
+            if (!s->halt && s->iter >= s->iter_end) { s->halt = SEG_HALT_WINDOW; if (!s->l2f) s->legacy_iter_p1 = s->iter + 1; }
+            if (!s->halt && do_prep) s->phase = 1;
         }
-        if (stopped) {
-            s.halt = SEG_HALT_STOP;
-            if (!s.l2f) { s.cur_obj = bin_cost; s.legacy_iter_p1 = it + 1; }   // legacy epilogue (:1371-1376)
-        } else s.iter = it + 1;
     }
-    if (!s.halt && s.iter >= s.iter_end) { s.halt = SEG_HALT_WINDOW; if (!s.l2f) s.legacy_iter_p1 = s.iter + 1; }
-    if (s.halt || !do_prep) { write_state(d, out, s); return; }
+    if (!will_prep) return;
     double pa[1] = {0.0};
     for (int q = 0; q < d.EPT; q++) {
         const int i = blockIdx.x * (T * d.EPT) + q * T + threadIdx.x;
         double c = 0.0;
-        if (i < d.n && d.live[i]) { const double u = (d.x[i] + d.z2[i] / s.rho2) - 0.5; c = u * u; }
+        if (i < d.n && d.live[i]) { const double u = (d.x[i] + d.z2[i] / rho2) - 0.5; c = u * u; }
         pa[0] = pa[0] + c;
     }
     store_partials<1>(d, PH_A, pa, red, parity);
-    s.phase = 1;
-    write_state(d, out, s);
 }
 
 __global__ void __launch_bounds__(T) seg_k_yrhs(SegDev d, int in, int out) {
     __shared__ double red[2 * RED_MAXV * RED_MAXW];
     int parity = 0;
-    SegState s = d.st[in];
-    if (s.halt) { write_state(d, out, s); return; }
+    const SegState *si = d.st + in;
+    if (si->halt) { forward_state(d, in, out); return; }
+    const double rho1 = si->rho1, rho2 = si->rho2, c1 = si->c1;
+    const int rhoUpdated = si->rhoUpdated, stale = si->dinv_stale;
+    const bool refresh = si->iter != 0 && rhoUpdated;
+    const double inc = (si->prev_rho1 + si->prev_rho2) * si->rcr;            // :1086
     double a[1];
     final_sums<1>(d, PH_A, a, red, parity);
     const double c2 = 2 * sqrt(a[0]);
-    const bool refresh = s.iter != 0 && s.rhoUpdated;
-    const double inc = (s.prev_rho1 + s.prev_rho2) * s.rcr;                  // :1086
     for (int q = 0; q < d.EPT; q++) {
         const int i = blockIdx.x * (T * d.EPT) + q * T + threadIdx.x;
         if (i >= d.n || !d.live[i]) continue;
         const double x = d.x[i], z1 = d.z1[i], z2 = d.z2[i];
-        const double t = x + z1 / s.rho1;
+        const double t = x + z1 / rho1;
         const double y1 = t > 1 ? 1 : (t < 0 ? 0 : t);
-        double y2 = (x + z2 / s.rho2) - 0.5;
-        y2 = y2 * s.c1 / c2 + 0.5;
+        double y2 = (x + z2 / rho2) - 0.5;
+        y2 = y2 * c1 / c2 + 0.5;
         d.y1[i] = y1; d.y2[i] = y2;
         double td = d.td[i];
         if (refresh) { td += inc; d.td[i] = td; }
-        if (s.rhoUpdated || s.dinv_stale) d.dinv[i] = td != 0.0 ? 1.0 / td : 1.0;   // DiagonalPreconditioner::compute (:1098-1101)
-        d.rhs[i] = (s.rho1 * y1 + s.rho2 * y2) - ((d.b[i] + z1) + z2);         // :1091
-        d.x[i] = y1;                                                          // x_sol = y1 (:1104)
+        if (rhoUpdated || stale) d.dinv[i] = td != 0.0 ? 1.0 / td : 1.0;    // DiagonalPreconditioner::compute (:1098-1101)
+        d.rhs[i] = (rho1 * y1 + rho2 * y2) - ((d.b[i] + z1) + z2);           // :1091
+        d.x[i] = y1;                                                         // x_sol = y1 (:1104)
     }
-    s.rhoUpdated = 0; s.dinv_stale = 0;
-    write_state(d, out, s);
+    if (LEADER) { d.st[out] = *si; d.st[out].rhoUpdated = 0; d.st[out].dinv_stale = 0; }
 }
 
 __global__ void __launch_bounds__(T) seg_k_resid(SegDev d, int in, int out) {
     __shared__ double red[2 * RED_MAXV * RED_MAXW];
     int parity = 0;
-    SegState s = d.st[in];
-    if (s.halt) { write_state(d, out, s); return; }
+    const SegState *si = d.st + in;
+    if (si->halt) { forward_state(d, in, out); return; }
     double pb[3] = {0.0, 0.0, 0.0};
     const double *x = d.x;
     for (int q = 0; q < d.EPT; q++) {
@@ -259,45 +282,51 @@ __global__ void __launch_bounds__(T) seg_k_resid(SegDev d, int in, int out) {
         pb[0] = pb[0] + c0; pb[1] = pb[1] + c1; pb[2] = pb[2] + c2;
     }
     store_partials<3>(d, PH_B, pb, red, parity);
-    s.pcg_k = 0; s.pcg_done = 0; s.phase = 2;
-    write_state(d, out, s);
+    if (LEADER) { d.st[out] = *si; d.st[out].pcg_k = 0; d.st[out].pcg_done = 0; d.st[out].phase = 2; }
 }
 
 // tmp = M p with the search-direction update of the previous PCG iteration folded in
 __global__ void __launch_bounds__(T) seg_k_matvec(SegDev d, int in, int out) {
     __shared__ double red[2 * RED_MAXV * RED_MAXW];
     int parity = 0;
-    SegState s = d.st[in];
-    if (s.halt || s.pcg_done || s.phase != 2) { write_state(d, out, s); return; }
+    const SegState *si = d.st + in;
+    if (si->halt || si->pcg_done || si->phase != 2) { forward_state(d, in, out); return; }
+    const int pcg_k = si->pcg_k;
+    double threshold = si->threshold, absNew = si->absNew, rhsNorm2 = si->rhsNorm2;
     double beta = 0.0;
-    bool first = s.pcg_k == 0, zero_x = false;
+    const bool first = pcg_k == 0;
+    bool done = false, zero_x = false;
     if (first) {
         double b3[3];
         final_sums<3>(d, PH_B, b3, red, parity);
-        s.rhsNorm2 = b3[0];
-        if (s.rhsNorm2 == 0) { s.pcg_done = 1; zero_x = true; }             // :265-271
+        rhsNorm2 = b3[0];
+        if (rhsNorm2 == 0) { done = true; zero_x = true; }                   // :265-271
         else {
-            double thr = SEG_PCG_TOL * SEG_PCG_TOL * s.rhsNorm2;             // :274
+            double thr = SEG_PCG_TOL * SEG_PCG_TOL * rhsNorm2;               // :274
             if (thr < DBL_MIN) thr = DBL_MIN;
-            s.threshold = thr;
-            if (b3[1] < thr) s.pcg_done = 1;                                  // :277
-            s.absNew = b3[2];
+            threshold = thr;
+            if (b3[1] < thr) done = true;                                     // :277
+            absNew = b3[2];
         }
     } else {
         double d2[2];
         final_sums<2>(d, PH_D, d2, red, parity);
-        if (d2[0] < s.threshold || s.pcg_k >= SEG_PCG_MAXITERS) s.pcg_done = 1;   // :304-307
-        else { const double absOld = s.absNew; s.absNew = d2[1]; beta = s.absNew / absOld; }   // :311-313
+        if (d2[0] < threshold || pcg_k >= SEG_PCG_MAXITERS) done = true;     // :304-307
+        else { const double absOld = absNew; absNew = d2[1]; beta = absNew / absOld; }   // :311-313
     }
-    if (s.pcg_done) {
+    if (LEADER) {
+        d.st[out] = *si;
+        SegState *s = d.st + out;
+        s->threshold = threshold; s->absNew = absNew; s->rhsNorm2 = rhsNorm2; s->pcg_done = done ? 1 : 0;
+    }
+    if (done) {
         if (zero_x)
             for (int q = 0; q < d.EPT; q++) { const int i = blockIdx.x * (T * d.EPT) + q * T + threadIdx.x; if (i < d.n) d.x[i] = 0.0; }
-        write_state(d, out, s);
         return;
     }
     // p buffers: iteration k reads p_old = buffer (k-1)&1 (k >= 1) and writes buffer k&1; k = 0 uses p0 as written by resid
-    const double *pold = ((s.pcg_k - 1) & 1) ? d.p1 : d.p0;
-    double *pnew = (s.pcg_k & 1) ? d.p1 : d.p0;
+    const double *pold = ((pcg_k - 1) & 1) ? d.p1 : d.p0;
+    double *pnew = (pcg_k & 1) ? d.p1 : d.p0;
     const double *zz = d.z;
     double pc[1] = {0.0};
     for (int q = 0; q < d.EPT; q++) {
@@ -320,18 +349,19 @@ __global__ void __launch_bounds__(T) seg_k_matvec(SegDev d, int in, int out) {
         pc[0] = pc[0] + c;
     }
     store_partials<1>(d, PH_C, pc, red, parity);
-    write_state(d, out, s);
 }
 
 __global__ void __launch_bounds__(T) seg_k_update(SegDev d, int in, int out) {
     __shared__ double red[2 * RED_MAXV * RED_MAXW];
     int parity = 0;
-    SegState s = d.st[in];
-    if (s.halt || s.pcg_done || s.phase != 2) { write_state(d, out, s); return; }
+    const SegState *si = d.st + in;
+    if (si->halt || si->pcg_done || si->phase != 2) { forward_state(d, in, out); return; }
+    const int pcg_k = si->pcg_k;
+    const double absNew = si->absNew;
     double c1[1];
     final_sums<1>(d, PH_C, c1, red, parity);
-    const double alpha = s.absNew / c1[0];                                    // :295
-    const double *p = (s.pcg_k & 1) ? d.p1 : d.p0;
+    const double alpha = absNew / c1[0];                                      // :295
+    const double *p = (pcg_k & 1) ? d.p1 : d.p0;
     double pd2[2] = {0.0, 0.0};
     for (int q = 0; q < d.EPT; q++) {
         const int i = blockIdx.x * (T * d.EPT) + q * T + threadIdx.x;
@@ -347,26 +377,26 @@ __global__ void __launch_bounds__(T) seg_k_update(SegDev d, int in, int out) {
         pd2[0] = pd2[0] + a; pd2[1] = pd2[1] + b2;
     }
     store_partials<2>(d, PH_D, pd2, red, parity);
-    s.pcg_k++;
-    write_state(d, out, s);
+    if (LEADER) { d.st[out] = *si; d.st[out].pcg_k = pcg_k + 1; }
 }
 
 __global__ void __launch_bounds__(T) seg_k_post(SegDev d, int in, int out) {
     __shared__ double red[2 * RED_MAXV * RED_MAXW];
     int parity = 0;
-    SegState s = d.st[in];
-    if (s.halt || s.phase != 2) { write_state(d, out, s); return; }
-    if (!s.pcg_done) {                     // the exit test of the last update is still pending
+    const SegState *si = d.st + in;
+    if (si->halt || si->phase != 2) { forward_state(d, in, out); return; }
+    const int pcg_k = si->pcg_k, l2f = si->l2f, cc = si->cc;
+    int done = si->pcg_done;
+    if (!done) {                           // the exit test of the last update is still pending
         double d2[2];
         final_sums<2>(d, PH_D, d2, red, parity);
-        if (s.pcg_k >= 1 && (d2[0] < s.threshold || s.pcg_k >= SEG_PCG_MAXITERS)) s.pcg_done = 1;
-        else { s.halt = SEG_HALT_PCG_MORE; write_state(d, out, s); return; }
+        if (pcg_k >= 1 && (d2[0] < si->threshold || pcg_k >= SEG_PCG_MAXITERS)) done = 1;
+        else { if (LEADER) { d.st[out] = *si; d.st[out].halt = SEG_HALT_PCG_MORE; } return; }
     }
-    s.last_pcg = s.pcg_k; s.pcg_total += s.pcg_k; s.outer_total++;
-    const double g1 = s.gamma_val * s.rho1, g2 = s.gamma_val * s.rho2;
+    const double g1 = si->gamma_val * si->rho1, g2 = si->gamma_val * si->rho2;
     const double *x = d.x;
     double e5[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, e2[2] = {0.0, 0.0};
-    double *xh = s.l2f ? d.xhist + (size_t)s.cc * d.n : nullptr;
+    double *xh = l2f ? d.xhist + (size_t)cc * d.n : nullptr;
     for (int q = 0; q < d.EPT; q++) {
         const int i = blockIdx.x * (T * d.EPT) + q * T + threadIdx.x;
         double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0, v4 = 0.0, v5 = 0.0, v6 = 0.0;
@@ -377,10 +407,10 @@ __global__ void __launch_bounds__(T) seg_k_post(SegDev d, int in, int out) {
             if (xh) xh[i] = xi;                                               // x_iters column (:1113-1116)
             // A x and A round(x) in one pass over the row (compute_cost :568-572, A_ptr restricted to the live variables)
             double t1 = 0, t2 = 0;
-            const int k1 = d.rowptr[i + 1];
-            for (int k = d.rowptr[i]; k < k1; k++) {
-                const int c = d.colidx[k];
-                const double xc = x[c], a = d.vals[k];
+            const int len = d.rowlen[i];
+            for (int k = 0; k < len; k++) {
+                const int c = d.ecol[(size_t)k * d.n + i];
+                const double xc = x[c], a = d.eval[(size_t)k * d.n + i];
                 t1 += a * xc;
                 t2 += a * (xc >= 0.5 ? 1.0 : 0.0);                           // fixed variables hold x = 0
             }
@@ -400,9 +430,14 @@ __global__ void __launch_bounds__(T) seg_k_post(SegDev d, int in, int out) {
         part_ptr(d, PH_E, 5)[blockIdx.x] = e2[0];
         part_ptr(d, PH_E, 6)[blockIdx.x] = e2[1];
     }
-    if (s.l2f) s.cc++;
-    s.have_prev = 1; s.phase = 0;
-    write_state(d, out, s);
+    if (LEADER) {
+        d.st[out] = *si;
+        SegState *s = d.st + out;
+        s->pcg_done = 1; s->last_pcg = pcg_k; s->pcg_total += pcg_k; s->outer_total++;
+        if (pcg_k > s->pcg_max) s->pcg_max = pcg_k;
+        if (l2f) s->cc = cc + 1;
+        s->have_prev = 1; s->phase = 0;
+    }
 }
 
 __global__ void seg_k_pack(SegDev d, const int *live_idx, int rows, int ws, double *out) {
@@ -451,15 +486,15 @@ hipError_t seg_enqueue_iterations(const SegDev &d, int iters, int kmax, int *par
 }
 
 hipError_t seg_enqueue_pcg_more(const SegDev &d, int pairs, int *parity, hipStream_t s) {
-    hipLaunchKernelGGL(seg_k_resume, dim3(1), dim3(1), 0, s, d, *parity, *parity ^ 1);
+    hipLaunchKernelGGL(seg_k_resume, dim3(1), dim3(1), 0, s, d, *parity, *parity ^ 1, 0);
     *parity ^= 1;
     for (int k = 0; k < pairs; k++) { SEG_LAUNCH(seg_k_matvec, d.G); SEG_LAUNCH(seg_k_update, d.G); }
     SEG_LAUNCH(seg_k_post, d.G);
     return hipGetLastError();
 }
 
-hipError_t seg_launch_copy(const SegDev &d, int *parity, hipStream_t s) {   // state copy only: flips the ping-pong parity
-    hipLaunchKernelGGL(seg_k_resume, dim3(1), dim3(1), 0, s, d, *parity, *parity ^ 1);
+hipError_t seg_launch_copy(const SegDev &d, int reset_pcg_max, int *parity, hipStream_t s) {   // state copy: flips the ping-pong parity
+    hipLaunchKernelGGL(seg_k_resume, dim3(1), dim3(1), 0, s, d, *parity, *parity ^ 1, reset_pcg_max);
     *parity ^= 1;
     return hipGetLastError();
 }
