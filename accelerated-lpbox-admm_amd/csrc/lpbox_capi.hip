@@ -95,7 +95,7 @@ struct lpbox_solver {
     double kernel_ms = 0.0;
     long long launches = 0;
     DevBuf<int> rs_ptr, cs_ptr, isc, ctl, left_idx, xi_rows;
-    DevBuf<uint16_t> rs_col, cs_row, rid, rmeta;
+    DevBuf<uint16_t> rs_col, cs_row, rid, rmeta, rgl;
     DevBuf<double> x, z1, z2, b, pd, z4, f, f_org, dsc, hist, dctl, c1_init, xhist, xi_out;
     DevBuf<uint8_t> live, newfix, live_init;
     DevBuf<unsigned long long> stamps;
@@ -110,7 +110,7 @@ struct lpbox_solver {
     LpBatchDev dev() const {
         LpBatchDev d;
         d.B = B; d.NS = NS; d.LS = LS; d.ZS = ZS;
-        d.rs_ptr = rs_ptr.p; d.rs_col = rs_col.p; d.cs_ptr = cs_ptr.p; d.cs_row = cs_row.p; d.rid = rid.p; d.rmeta = rmeta.p;
+        d.rs_ptr = rs_ptr.p; d.rs_col = rs_col.p; d.cs_ptr = cs_ptr.p; d.cs_row = cs_row.p; d.rid = rid.p; d.rmeta = rmeta.p; d.rgl = rgl.p;
         d.x = x.p; d.z1 = z1.p; d.z2 = z2.p; d.b = b.p; d.pd = pd.p; d.live = live.p; d.newfix = newfix.p;
         d.z4 = z4.p; d.f = f.p; d.dsc = dsc.p; d.isc = isc.p; d.hist = hist.p;
         d.ctl = ctl.p; d.dctl = dctl.p; d.xhist = xhist.p; d.ws_cap = ws_cap; d.stamps = stamps.p;
@@ -168,7 +168,7 @@ int finalize(lpbox_t *h) {
         return fail(LPBOX_E_UNSUPPORTED, "instance with max(n,l)=%d exceeds the on-chip kernel's %d register slots", big, T * EPT);
     h->T = T; h->EPT = EPT;
     h->NS = T * EPT;                       // storage positions / row-task slots per instance
-    h->LS = (lmax + 7) & ~7; h->ZS = (zmax + 7) & ~7;
+    h->LS = (lmax + 31) & ~31; h->ZS = (zmax + 7) & ~7;     // LS: a whole number of 32-row bank classes
     h->lds = lp_window_lds_bytes(T, h->NS, h->LS, h->ZS);
     if (h->lds > 160 * 1024) return fail(LPBOX_E_UNSUPPORTED, "instance needs %zu B of LDS (> 160 KiB per CU)", h->lds);
 
@@ -176,7 +176,7 @@ int finalize(lpbox_t *h) {
     if (!h->ev0) { HIPCHK(hipEventCreate(&h->ev0)); HIPCHK(hipEventCreate(&h->ev1)); }
     const size_t B = h->B, NS = h->NS, LS = h->LS, ZS = h->ZS;
     HIPCHK(h->rs_ptr.alloc(B * (NS + 1))); HIPCHK(h->cs_ptr.alloc(B * (NS + 1)));
-    HIPCHK(h->rs_col.alloc(B * ZS)); HIPCHK(h->cs_row.alloc(B * ZS)); HIPCHK(h->rid.alloc(B * NS)); HIPCHK(h->rmeta.alloc(B * NS));
+    HIPCHK(h->rs_col.alloc(B * ZS)); HIPCHK(h->cs_row.alloc(B * ZS)); HIPCHK(h->rid.alloc(B * NS)); HIPCHK(h->rmeta.alloc(B * NS)); HIPCHK(h->rgl.alloc(B * NS));
     HIPCHK(h->live_init.alloc(B * NS));
     HIPCHK(h->x.alloc(B * NS)); HIPCHK(h->z1.alloc(B * NS)); HIPCHK(h->z2.alloc(B * NS));
     HIPCHK(h->b.alloc(B * NS)); HIPCHK(h->pd.alloc(B * NS));
@@ -190,7 +190,7 @@ int finalize(lpbox_t *h) {
 #endif
 
     std::vector<int> h_rs_ptr(B * (NS + 1), 0), h_cs_ptr(B * (NS + 1), 0), h_isc(B * NI_COUNT, 0);
-    std::vector<uint16_t> h_rs_col(B * ZS, 0), h_cs_row(B * ZS, 0), h_rid(B * NS, 0xFFFF), h_rmeta(B * NS, 0x10);
+    std::vector<uint16_t> h_rs_col(B * ZS, 0), h_cs_row(B * ZS, 0), h_rid(B * NS, 0xFFFF), h_rgl(B * NS, 0), h_rmeta(B * NS, 0x10);
     std::vector<uint8_t> h_live(B * NS, 0);
     std::vector<double> h_b(B * NS, 0.0), h_f(B * LS, 0.0), h_c1(B, 0.0);
     const bool nosort = getenv("LPBOX_LP_NOSORT") != nullptr;
@@ -203,30 +203,9 @@ int finalize(lpbox_t *h) {
         const int wv = (slot & 1) ? (W - 1 - r) : r;
         return slot * h->T + wv * 64;
     };
+    const bool noconflict = getenv("LPBOX_LP_NOCONFLICT") != nullptr;
     for (size_t i = 0; i < B; i++) {
         LpInstance &I = h->inst[i];
-        // ---- columns: variable j -> storage position cpos[j], by decreasing column length (stable) ----
-        I.cperm.resize(I.n); I.cpos.resize(I.n);
-        for (int j = 0; j < I.n; j++) I.cperm[j] = j;
-        if (!nosort)
-            std::stable_sort(I.cperm.begin(), I.cperm.end(), [&](int a, int c) {
-                return I.colptr[a + 1] - I.colptr[a] > I.colptr[c + 1] - I.colptr[c]; });
-        std::vector<int> var_of_pos(NS, -1);
-        for (int q = 0; q < I.n; q++) {
-            const int p = nosort ? q : block_base(q / 64) + q % 64;
-            I.cpos[I.cperm[q]] = p;
-            var_of_pos[p] = I.cperm[q];
-        }
-        int k = 0;
-        for (size_t p = 0; p < NS; p++) {
-            h_cs_ptr[i * (NS + 1) + p] = k;
-            const int j = var_of_pos[p];
-            if (j < 0) continue;
-            for (int e = I.colptr[j]; e < I.colptr[j + 1]; e++) h_cs_row[i * ZS + k++] = (uint16_t)I.rowidx[e];
-            h_b[i * NS + p] = I.b[j];
-            h_live[i * NS + p] = 1;
-        }
-        h_cs_ptr[i * (NS + 1) + NS] = k;
         // ---- rows: G lanes share a row so that no lane walks more than ~L entries; lane g takes entries g, g+G, ... ----
         I.rowG.assign(I.l, 1);
         if (!nosplit) {
@@ -252,12 +231,103 @@ int finalize(lpbox_t *h) {
             std::stable_sort(rorder.begin(), rorder.end(), [&](int a, int c) { return I.rowG[a] > I.rowG[c]; });
         struct Task { int row, g, G; };
         std::vector<Task> task_of_slot(NS, Task{-1, 0, 1});
-        int q = 0;
-        for (int r : rorder)
+        std::vector<int> slot_of_row(I.l, 0);          // storage slot of lane 0 of the row's task group (lanes are consecutive)
+        int q = 0, max_chain = 1;
+        for (int r : rorder) {
+            max_chain = std::max(max_chain, chain(r));
             for (int g = 0; g < I.rowG[r]; g++, q++) {
                 const int tp = nosort ? q : block_base(q / 64) + q % 64;
+                if (g == 0) slot_of_row[r] = tp;
                 task_of_slot[tp] = Task{r, g, I.rowG[r]};
             }
+        }
+        // ---- columns: variable j -> storage position cpos[j].  Blocks of 64 by decreasing column length (stable) are dealt
+        // to the waves; INSIDE a block the lane (= LDS bank class pos % 32 of the variable in the gathered vector) is chosen
+        // greedily so that the 32 lanes of a half-wave gather from different banks in as many row-gather instructions as
+        // possible (an instruction = the k-th list entry of the 32 row tasks of one half-wave).
+        I.cperm.resize(I.n); I.cpos.resize(I.n);
+        for (int j = 0; j < I.n; j++) I.cperm[j] = j;
+        if (!nosort)
+            std::stable_sort(I.cperm.begin(), I.cperm.end(), [&](int a, int c) {
+                return I.colptr[a + 1] - I.colptr[a] > I.colptr[c + 1] - I.colptr[c]; });
+        std::vector<int> var_of_pos(NS, -1);
+        if (nosort || noconflict) {
+            for (int qq = 0; qq < I.n; qq++) {
+                const int p = nosort ? qq : block_base(qq / 64) + qq % 64;
+                I.cpos[I.cperm[qq]] = p; var_of_pos[p] = I.cperm[qq];
+            }
+        } else {
+            // occurrences of column j in the row-gather instructions: (half-wave group of the task slot, entry index k)
+            std::vector<std::vector<std::pair<int, int>>> occ(I.n);
+            for (int r = 0; r < I.l; r++) {
+                const int G = I.rowG[r];
+                for (int e = I.rowptr[r]; e < I.rowptr[r + 1]; e++) {
+                    const int ee = e - I.rowptr[r];
+                    occ[I.colidx[e]].push_back({(slot_of_row[r] + ee % G) / 32, ee / G});
+                }
+            }
+            const int ngrp = (int)NS / 32;
+            std::vector<int> cnt((size_t)ngrp * max_chain * 32, 0);
+            for (int blk = 0; blk * 64 < I.n; blk++) {
+                bool used[64] = {false};
+                const int base = block_base(blk);
+                for (int qq = blk * 64; qq < std::min(I.n, blk * 64 + 64); qq++) {
+                    const int j = I.cperm[qq];
+                    int best = -1; long best_cost = 0;
+                    for (int c = 0; c < 32; c++) {
+                        if (used[c] && used[c + 32]) continue;
+                        long cost = 0;
+                        for (auto &o : occ[j]) cost += cnt[((size_t)o.first * max_chain + o.second) * 32 + c];
+                        if (best < 0 || cost < best_cost) { best = c; best_cost = cost; }
+                    }
+                    const int lane = used[best] ? best + 32 : best;
+                    used[lane] = true;
+                    for (auto &o : occ[j]) cnt[((size_t)o.first * max_chain + o.second) * 32 + best]++;
+                    I.cpos[j] = base + lane; var_of_pos[base + lane] = j;
+                }
+            }
+        }
+        int k = 0;
+        // ---- row storage index in the gathered l-vectors (bank class rpos % 32), chosen the same way for the column gathers ----
+        std::vector<int> rpos(I.l);
+        for (int r = 0; r < I.l; r++) rpos[r] = r;
+        if (!nosort && !noconflict) {
+            int max_col = 1;
+            for (int j = 0; j < I.n; j++) max_col = std::max(max_col, I.colptr[j + 1] - I.colptr[j]);
+            const int ngrp = (int)NS / 32, cap = (int)LS / 32;
+            std::vector<int> cnt((size_t)ngrp * max_col * 32, 0), usedc(32, 0);
+            std::vector<int> order(I.l);
+            for (int r = 0; r < I.l; r++) order[r] = r;
+            std::stable_sort(order.begin(), order.end(), [&](int a, int c) { return I.rowptr[a + 1] - I.rowptr[a] > I.rowptr[c + 1] - I.rowptr[c]; });
+            // rank of row r inside column j's (ascending) row list = its entry index in the column gather
+            auto rank_in_col = [&](int j, int r) { return (int)(std::lower_bound(I.rowidx.begin() + I.colptr[j], I.rowidx.begin() + I.colptr[j + 1], r) - (I.rowidx.begin() + I.colptr[j])); };
+            for (int r : order) {
+                int best = -1; long best_cost = 0;
+                for (int c = 0; c < 32; c++) {
+                    if (usedc[c] >= cap) continue;
+                    long cost = 0;
+                    for (int e = I.rowptr[r]; e < I.rowptr[r + 1]; e++) {
+                        const int j = I.colidx[e];
+                        cost += cnt[((size_t)(I.cpos[j] / 32) * max_col + rank_in_col(j, r)) * 32 + c];
+                    }
+                    if (best < 0 || cost < best_cost) { best = c; best_cost = cost; }
+                }
+                for (int e = I.rowptr[r]; e < I.rowptr[r + 1]; e++) {
+                    const int j = I.colidx[e];
+                    cnt[((size_t)(I.cpos[j] / 32) * max_col + rank_in_col(j, r)) * 32 + best]++;
+                }
+                rpos[r] = best + 32 * usedc[best]++;
+            }
+        }
+        for (size_t p = 0; p < NS; p++) {
+            h_cs_ptr[i * (NS + 1) + p] = k;
+            const int j = var_of_pos[p];
+            if (j < 0) continue;
+            for (int e = I.colptr[j]; e < I.colptr[j + 1]; e++) h_cs_row[i * ZS + k++] = (uint16_t)rpos[I.rowidx[e]];
+            h_b[i * NS + p] = I.b[j];
+            h_live[i * NS + p] = 1;
+        }
+        h_cs_ptr[i * (NS + 1) + NS] = k;
         k = 0;
         for (size_t tp = 0; tp < NS; tp++) {
             h_rs_ptr[i * (NS + 1) + tp] = k;
@@ -265,6 +335,7 @@ int finalize(lpbox_t *h) {
             if (t.row < 0) continue;
             for (int e = I.rowptr[t.row] + t.g; e < I.rowptr[t.row + 1]; e += t.G) h_rs_col[i * ZS + k++] = (uint16_t)I.cpos[I.colidx[e]];
             h_rid[i * NS + tp] = (uint16_t)t.row;
+            h_rgl[i * NS + tp] = (uint16_t)rpos[t.row];
             h_rmeta[i * NS + tp] = (uint16_t)((t.G << 4) | t.g);
         }
         h_rs_ptr[i * (NS + 1) + NS] = k;
@@ -274,6 +345,7 @@ int finalize(lpbox_t *h) {
         h_c1[i] = std::pow((double)I.n, 1.0 / 2);     // std::pow(n, 1.0/p), p = projection_lp = 2 (LPcpp:427,503)
     }
     HIPCHK(hipMemcpy(h->rmeta.p, h_rmeta.data(), h_rmeta.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->rgl.p, h_rgl.data(), h_rgl.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->live_init.p, h_live.data(), h_live.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->rs_ptr.p, h_rs_ptr.data(), h_rs_ptr.size() * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->cs_ptr.p, h_cs_ptr.data(), h_cs_ptr.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -400,7 +472,7 @@ void lpbox_destroy(lpbox_t *h) {
     if (h->finalized) (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->rs_ptr.release(); h->cs_ptr.release(); h->isc.release(); h->ctl.release(); h->left_idx.release(); h->xi_rows.release();
-    h->rs_col.release(); h->cs_row.release(); h->rid.release(); h->rmeta.release(); h->live_init.release();
+    h->rs_col.release(); h->cs_row.release(); h->rid.release(); h->rmeta.release(); h->rgl.release(); h->live_init.release();
     h->x.release(); h->z1.release(); h->z2.release(); h->b.release(); h->pd.release(); h->z4.release(); h->f.release();
     h->f_org.release(); h->dsc.release(); h->hist.release(); h->dctl.release(); h->c1_init.release(); h->xhist.release();
     h->xi_out.release(); h->live.release(); h->newfix.release(); h->stamps.release();

@@ -50,6 +50,7 @@ struct LpBatchDev {
     const int *rs_ptr; const uint16_t *rs_col;   // row slot q: positions of its columns, ascending ORIGINAL column index
     const int *cs_ptr; const uint16_t *cs_row;   // position p: original row ids of its column, ascending
     const uint16_t *rid;      // row-task slot -> original row id (0xFFFF = no task)
+    const uint16_t *rgl;      // row-task slot -> storage index of the row inside the gathered LDS l-vectors (bank-conflict aware)
     const uint16_t *rmeta;    // row-task slot -> (G << 4) | g: lane g of the G lanes sharing the row
     // state
     double *x, *z1, *z2, *b, *pd;

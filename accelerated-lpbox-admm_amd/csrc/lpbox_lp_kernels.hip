@@ -305,6 +305,7 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
     bool rvalid[EPT];       // this lane is the LEADER (lane 0) of a row task: it owns the row's l-vector entries
     bool rtask[EPT];        // this lane takes part in a row sum
     int rrow[EPT];          // original row id of the row task in slot s
+    int rgl[EPT];           // storage index of that row in the gathered LDS l-vectors
     int rG[EPT];            // lanes sharing that row (1,2,4,8)
 #pragma unroll
     for (int s = 0; s < EPT; s++) {
@@ -317,6 +318,7 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
         rtask[s] = rid != 0xFFFF;
         rvalid[s] = rtask[s] && (meta & 15) == 0;
         rrow[s] = rtask[s] ? rid : 0;
+        rgl[s] = rtask[s] ? (int)bd.rgl[on + pos] : 0;
         rG[s] = rtask[s] ? (meta >> 4) : 1;
         z4[s] = f[s] = 0.0;
         if (rvalid[s]) { z4[s] = bd.z4[ol + rrow[s]]; f[s] = bd.f[ol + rrow[s]]; }
@@ -458,7 +460,7 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
             for (int s = 0; s < EPT; s++) {
                 const double v = f[s] - Ex[s] - z4[s] / rho4;
                 y3[s] = v < 0 ? 0 : v;
-                if (rvalid[s]) { gl[3 * rrow[s]] = f[s] - y3[s]; gl[3 * rrow[s] + 1] = z4[s]; }
+                if (rvalid[s]) { gl[3 * rgl[s]] = f[s] - y3[s]; gl[3 * rgl[s] + 1] = z4[s]; }
                 if (valid[s]) gx[s * T + tid] = live[s] ? y1[s] : 0.0;      // PCG start x0 = y1 (:892)
             }
             __syncthreads();
@@ -495,7 +497,7 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
                 double q[EPT];
                 rows_gather(q);
 #pragma unroll
-                for (int s = 0; s < EPT; s++) if (rvalid[s]) gl[3 * rrow[s] + 2] = q[s];
+                for (int s = 0; s < EPT; s++) if (rvalid[s]) gl[3 * rgl[s] + 2] = q[s];
             }
             __syncthreads();
             if (rhoUpdated) {                                         // DiagonalPreconditioner::compute (:883-890)
@@ -545,7 +547,7 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
                             rows_gather(q);
                             STAMP(4)
 #pragma unroll
-                            for (int s = 0; s < EPT; s++) if (rvalid[s]) gl[3 * rrow[s]] = q[s];
+                            for (int s = 0; s < EPT; s++) if (rvalid[s]) gl[3 * rgl[s]] = q[s];
                         }
                         __syncthreads();
                         STAMP(5)
