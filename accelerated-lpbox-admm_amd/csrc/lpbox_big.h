@@ -1,0 +1,61 @@
+// lpbox_big.h -- internal layout of the LARGE-instance LP path (BASELINE config 5: one LP with up to ~1e6 variables,
+// variable-sharded over the GPUs of a node).  Not part of the C-ABI.
+//
+// A rank owns the contiguous column block [c0, c1) of E (all rows): its n-vectors x, y1, y2, z1, z2, b, ... are local,
+// the l-vectors y3, z4, f, E*x, E*p are REPLICATED (every rank computes all l entries).  One ADMM iteration is a chain of
+// kernels cut at the grid-wide dependencies; where the algorithm needs a sum over all variables the chain has a collective:
+//   * E*v  = sum over ranks of E[:, shard] * v_shard      -> all-reduce of an l-vector (once per PCG iteration + 2 per outer)
+//   * dot products / norms                                 -> all-reduce of <= 5 scalars
+// (north_star's "one all-reduce per iteration" under-counts: SURVEY section 8e.)  With one rank the collectives vanish and
+// the path is bit-comparable with the oracle (two-level reduction order, rows and columns summed in ascending order).
+// Control state lives on the device (BigState, ping-ponged), kernels fall through once the PCG has converged / the solver
+// has stopped, so the host enqueues a static sequence.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lpbox_lp.h"   // hyper-parameters LP_* (LPcpp:491-507) and stop reasons
+
+#define BIG_T 256
+#define BIG_NPART 8
+
+enum { BIG_HALT_NONE = 0, BIG_HALT_STOP = 1, BIG_HALT_WINDOW = 2, BIG_HALT_PCG_MORE = 3 };
+
+struct BigState {
+    double rho1, rho2, rho4, prev_rho1, prev_rho2, prev_rho4, gamma_val, dI, r4Et, rcr;
+    double std_obj, cur_obj, best_bin_obj, cvg1, cvg2, obj_val, c1;
+    double hist[LP_HIST];
+    double threshold, absNew, rhsNorm2, beta;
+    int rhoUpdated, hist_n, iter, iter_start, iter_end, have_prev, halt, stop, ret;
+    int pcg_k, pcg_done, pcg_first, phase;
+    int pcg_total, outer_total, last_pcg, plain_iter_p1, pcg_max, expr_ready;
+    int pad0;
+};
+
+struct BigDev {
+    int n_loc, l, G, Gl, EPT, EPTl;       // G workgroups over the local variables, Gl over the rows
+    long n_glob;
+    // E restricted to the local columns: CSR (rows -> local column index) and CSC (local column -> rows), values all 1
+    const int *rptr, *rcol, *cptr, *crow;
+    double *x, *y1, *y2, *z1, *z2, *b, *pd, *dinv, *rhs, *r, *z, *tmp, *p0, *p1, *gsrc;   // local n-vectors
+    double *y3, *z4, *f, *fy, *Ex, *q;    // replicated l-vectors (q doubles as the all-reduce buffer of E*v)
+    double *part;                         // [BIG_NPART][G] workgroup partials
+    double *red;                          // [BIG_NPART] reduced scalars (all-reduced over the ranks)
+    BigState *st;                         // st[0], st[1]
+};
+
+// launch helpers (lpbox_big_kernels.hip); every state-carrying launch reads st[*parity], writes st[*parity^1], flips *parity
+hipError_t big_launch_init(const BigDev &d, double c1, hipStream_t s);      // state, x = 1, partial b.x0 -> red[0]
+hipError_t big_launch_init2(const BigDev &d, hipStream_t s);               // best_bin_obj = red[0] (after the all-reduce)
+hipError_t big_launch_set_window(const BigDev &d, int iter_start, int iter_end, int *parity, hipStream_t s);
+hipError_t big_launch_prep(const BigDev &d, int do_prep, int *parity, hipStream_t s);
+hipError_t big_launch_fin(const BigDev &d, int nv, hipStream_t s);                    // partials -> red[0..nv)
+hipError_t big_launch_y(const BigDev &d, int *parity, hipStream_t s);                 // y1, y2, refresh, rhs base, y3 (all rows)
+hipError_t big_launch_rhs_cols(const BigDev &d, int *parity, hipStream_t s);          // rhs += r4Et E^T(f-y3) - E^T z4
+hipError_t big_launch_rows(const BigDev &d, int mode, int *parity, hipStream_t s);    // q = E[:,shard] * v  (mode 0: gsrc, 1: PCG p)
+hipError_t big_launch_resid(const BigDev &d, int *parity, hipStream_t s);
+hipError_t big_launch_pcg_cols(const BigDev &d, int *parity, hipStream_t s);
+hipError_t big_launch_pcg_upd(const BigDev &d, int *parity, hipStream_t s);
+hipError_t big_launch_post(const BigDev &d, int *parity, hipStream_t s);              // duals z1,z2, partials(5), gsrc = x
+hipError_t big_launch_z4(const BigDev &d, int init_only, int *parity, hipStream_t s); // Ex = q [, z4 update]
+hipError_t big_launch_resume(const BigDev &d, int reset_pcg_max, int *parity, hipStream_t s);

@@ -1,0 +1,300 @@
+// lpbox_big_capi.hip -- host side + C-ABI of the LARGE-instance LP path (lpbox_big_* in include/lpbox_hip.h):
+// one LP, variable-sharded over ranks (one process per GPU).  The library launches the kernels; where the algorithm needs a
+// sum over all variables it calls the caller-supplied all-reduce (RCCL through torch.distributed in lpbox_hip/big.py) on
+// the same HIP stream.  With one rank no collective is issued.
+#include "../../include/lpbox_hip.h"
+#include "lpbox_big.h"
+#include "lpbox_capi_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#define HIPCHK(expr)                                                                                         \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess) return lpbox_fail(LPBOX_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+namespace {
+template <typename Tp>
+struct Buf {
+    Tp *p = nullptr; size_t count = 0;
+    hipError_t alloc(size_t c) { release(); count = c; return c ? hipMalloc((void **)&p, c * sizeof(Tp)) : hipSuccess; }
+    void release() { if (p) (void)hipFree(p); p = nullptr; count = 0; }
+};
+}  // namespace
+
+struct lpbox_big {
+    int rank = 0, world = 1, device = 0;
+    long n_glob = 0; int c0 = 0, n_loc = 0, l = 0, nnz = 0;
+    std::vector<int> cptr, crow, rptr, rcol;
+    std::vector<double> b, f;
+    bool has_problem = false, uploaded = false, inited = false, own_stream = false;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    lpbox_allreduce_fn ar = nullptr; void *ar_user = nullptr;
+    int G = 0, Gl = 0, EPT = 2, EPTl = 2, kmax = 28, parity = 0;
+    bool adaptive = true;
+    double kernel_ms = 0.0; long long launches = 0, collectives = 0;
+    Buf<int> d_rptr, d_rcol, d_cptr, d_crow;
+    Buf<double> x, y1, y2, z1, z2, db, pd, dinv, rhs, r, z, tmp, p0, p1, gsrc, y3, z4, df, fy, Ex, q, part, red;
+    double *ext_q = nullptr, *ext_red = nullptr;     // caller-owned exchange buffers (e.g. torch tensors), optional
+    Buf<BigState> st;
+    BigState hst;
+
+    BigDev dev() const {
+        BigDev d;
+        d.n_loc = n_loc; d.l = l; d.G = G; d.Gl = Gl; d.EPT = EPT; d.EPTl = EPTl; d.n_glob = n_glob;
+        d.rptr = d_rptr.p; d.rcol = d_rcol.p; d.cptr = d_cptr.p; d.crow = d_crow.p;
+        d.x = x.p; d.y1 = y1.p; d.y2 = y2.p; d.z1 = z1.p; d.z2 = z2.p; d.b = db.p; d.pd = pd.p; d.dinv = dinv.p; d.rhs = rhs.p;
+        d.r = r.p; d.z = z.p; d.tmp = tmp.p; d.p0 = p0.p; d.p1 = p1.p; d.gsrc = gsrc.p;
+        d.y3 = y3.p; d.z4 = z4.p; d.f = df.p; d.fy = fy.p; d.Ex = Ex.p; d.q = ext_q ? ext_q : q.p; d.part = part.p; d.red = ext_red ? ext_red : red.p; d.st = st.p;
+        return d;
+    }
+};
+
+namespace {
+
+int use_device(lpbox_big *h) {
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) return lpbox_fail(LPBOX_E_NODEVICE, "no HIP device available");
+    HIPCHK(hipSetDevice(h->device));
+    return LPBOX_OK;
+}
+
+int allreduce(lpbox_big *h, double *ptr, long count) {
+    if (h->world <= 1) return LPBOX_OK;
+    if (!h->ar) return lpbox_fail(LPBOX_E_STATE, "world = %d but no all-reduce callback was set", h->world);
+    h->collectives++;
+    const int rc = h->ar(ptr, count, h->ar_user);
+    if (rc != 0) return lpbox_fail(LPBOX_E_HIP, "all-reduce callback failed (%d)", rc);
+    return LPBOX_OK;
+}
+
+#define CHK(expr) do { int rc_ = (expr); if (rc_ < 0) return rc_; } while (0)
+#define FIN(nv) do { HIPCHK(big_launch_fin(d, nv, h->stream)); h->launches++; CHK(allreduce(h, d.red, nv)); } while (0)
+#define ROWS(mode) do { HIPCHK(big_launch_rows(d, mode, &h->parity, h->stream)); h->launches++; CHK(allreduce(h, d.q, h->l)); } while (0)
+
+int enqueue_pcg(lpbox_big *h, const BigDev &d, int pairs) {
+    for (int k = 0; k < pairs; k++) {
+        ROWS(1);
+        HIPCHK(big_launch_pcg_cols(d, &h->parity, h->stream)); h->launches++;
+        FIN(1);
+        HIPCHK(big_launch_pcg_upd(d, &h->parity, h->stream)); h->launches++;
+        FIN(2);
+    }
+    return LPBOX_OK;
+}
+
+int enqueue_tail(lpbox_big *h, const BigDev &d) {
+    HIPCHK(big_launch_post(d, &h->parity, h->stream)); h->launches++;
+    FIN(5);
+    ROWS(0);
+    HIPCHK(big_launch_z4(d, 0, &h->parity, h->stream)); h->launches++;
+    return LPBOX_OK;
+}
+
+int enqueue_iteration(lpbox_big *h, const BigDev &d) {
+    HIPCHK(big_launch_prep(d, 1, &h->parity, h->stream)); h->launches++;
+    FIN(1);
+    HIPCHK(big_launch_y(d, &h->parity, h->stream)); h->launches++;
+    HIPCHK(big_launch_rhs_cols(d, &h->parity, h->stream)); h->launches++;
+    ROWS(0);
+    HIPCHK(big_launch_resid(d, &h->parity, h->stream)); h->launches++;
+    FIN(3);
+    CHK(enqueue_pcg(h, d, h->kmax));
+    return enqueue_tail(h, d);
+}
+
+int read_state(lpbox_big *h) {
+    HIPCHK(hipMemcpyAsync(&h->hst, h->st.p + h->parity, sizeof(BigState), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return LPBOX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+lpbox_big_t *lpbox_big_create(int rank, int world, int device) {
+    if (world < 1 || rank < 0 || rank >= world) { lpbox_fail(LPBOX_E_BADARG, "bad rank/world %d/%d", rank, world); return nullptr; }
+    lpbox_big *h = new lpbox_big();
+    h->rank = rank; h->world = world; h->device = device;
+    memset(&h->hst, 0, sizeof(h->hst));
+    if (const char *e = getenv("LPBOX_BIG_KMAX")) { int v = atoi(e); if (v >= 1 && v <= 1000) { h->kmax = v; h->adaptive = false; } }
+    return h;
+}
+
+void lpbox_big_destroy(lpbox_big_t *h) {
+    if (!h) return;
+    if (h->uploaded) (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    h->d_rptr.release(); h->d_rcol.release(); h->d_cptr.release(); h->d_crow.release();
+    for (Buf<double> *bp : {&h->x, &h->y1, &h->y2, &h->z1, &h->z2, &h->db, &h->pd, &h->dinv, &h->rhs, &h->r, &h->z, &h->tmp, &h->p0, &h->p1,
+                            &h->gsrc, &h->y3, &h->z4, &h->df, &h->fy, &h->Ex, &h->q, &h->part, &h->red})
+        bp->release();
+    h->st.release();
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int lpbox_big_set_stream(lpbox_big_t *h, void *hip_stream) {
+    if (!h) return lpbox_fail(LPBOX_E_BADHANDLE, "bad handle");
+    if (h->own_stream && h->stream) { (void)hipStreamDestroy(h->stream); h->own_stream = false; }
+    h->stream = (hipStream_t)hip_stream;
+    return LPBOX_OK;
+}
+
+int lpbox_big_set_exchange(lpbox_big_t *h, void *q_dev, void *red_dev) {
+    if (!h) return lpbox_fail(LPBOX_E_BADHANDLE, "bad handle");
+    if (h->inited) return lpbox_fail(LPBOX_E_STATE, "exchange buffers must be set before solve_init");
+    h->ext_q = (double *)q_dev; h->ext_red = (double *)red_dev;
+    return LPBOX_OK;
+}
+
+int lpbox_big_set_allreduce(lpbox_big_t *h, lpbox_allreduce_fn fn, void *user) {
+    if (!h) return lpbox_fail(LPBOX_E_BADHANDLE, "bad handle");
+    h->ar = fn; h->ar_user = user;
+    return LPBOX_OK;
+}
+
+int lpbox_big_set_problem(lpbox_big_t *h, long n_glob, int c0, int n_loc, int l, const int *colptr, const int *rowidx,
+                          const double *b, const double *f) {
+    if (!h) return lpbox_fail(LPBOX_E_BADHANDLE, "bad handle");
+    if (h->uploaded) return lpbox_fail(LPBOX_E_STATE, "problem already uploaded");
+    if (n_glob <= 0 || n_loc <= 0 || l <= 0 || c0 < 0 || (long)c0 + n_loc > n_glob || !colptr || !b || colptr[0] != 0)
+        return lpbox_fail(LPBOX_E_BADARG, "bad problem arguments");
+    const int nnz = colptr[n_loc];
+    for (int j = 0; j < n_loc; j++) {
+        if (colptr[j + 1] < colptr[j]) return lpbox_fail(LPBOX_E_BADARG, "colptr not monotone");
+        for (int k = colptr[j]; k < colptr[j + 1]; k++) {
+            if (rowidx[k] < 0 || rowidx[k] >= l) return lpbox_fail(LPBOX_E_BADARG, "row index out of range");
+            if (k > colptr[j] && rowidx[k] <= rowidx[k - 1]) return lpbox_fail(LPBOX_E_BADARG, "row indices must ascend inside a column");
+        }
+    }
+    h->n_glob = n_glob; h->c0 = c0; h->n_loc = n_loc; h->l = l; h->nnz = nnz;
+    h->cptr.assign(colptr, colptr + n_loc + 1); h->crow.assign(rowidx, rowidx + nnz);
+    h->rptr.assign((size_t)l + 1, 0);
+    for (int k = 0; k < nnz; k++) h->rptr[rowidx[k] + 1]++;
+    for (int i = 0; i < l; i++) h->rptr[i + 1] += h->rptr[i];
+    h->rcol.assign(nnz, 0);
+    std::vector<int> cur(h->rptr.begin(), h->rptr.end() - 1);
+    for (int j = 0; j < n_loc; j++) for (int k = colptr[j]; k < colptr[j + 1]; k++) h->rcol[cur[rowidx[k]]++] = j;
+    h->b.assign(b, b + n_loc);
+    if (f) h->f.assign(f, f + l); else h->f.assign(l, 1.0);
+    h->has_problem = true;
+    return LPBOX_OK;
+}
+
+int lpbox_big_init(lpbox_big_t *h) {
+    if (!h) return lpbox_fail(LPBOX_E_BADHANDLE, "bad handle");
+    if (!h->has_problem) return lpbox_fail(LPBOX_E_STATE, "no problem set");
+    CHK(use_device(h));
+    if (!h->uploaded) {
+        const int n = h->n_loc, l = h->l;
+        h->EPT = 2; while ((n + BIG_T * h->EPT - 1) / (BIG_T * h->EPT) > 2 * BIG_T * 8 && h->EPT < 64) h->EPT *= 2;
+        h->G = (n + BIG_T * h->EPT - 1) / (BIG_T * h->EPT);
+        h->EPTl = 2; h->Gl = (l + BIG_T * h->EPTl - 1) / (BIG_T * h->EPTl);
+        if (!h->stream) { HIPCHK(hipStreamCreate(&h->stream)); h->own_stream = true; }
+        HIPCHK(hipEventCreate(&h->ev0)); HIPCHK(hipEventCreate(&h->ev1));
+        HIPCHK(h->d_rptr.alloc((size_t)l + 1)); HIPCHK(h->d_rcol.alloc(h->nnz)); HIPCHK(h->d_cptr.alloc((size_t)n + 1)); HIPCHK(h->d_crow.alloc(h->nnz));
+        for (Buf<double> *bp : {&h->x, &h->y1, &h->y2, &h->z1, &h->z2, &h->db, &h->pd, &h->dinv, &h->rhs, &h->r, &h->z, &h->tmp, &h->p0, &h->p1, &h->gsrc})
+            HIPCHK(bp->alloc(n));
+        for (Buf<double> *bp : {&h->y3, &h->z4, &h->df, &h->fy, &h->Ex, &h->q}) HIPCHK(bp->alloc(l));
+        HIPCHK(h->part.alloc((size_t)BIG_NPART * h->G)); HIPCHK(h->red.alloc(BIG_NPART)); HIPCHK(h->st.alloc(2));
+        HIPCHK(hipMemcpy(h->d_rptr.p, h->rptr.data(), sizeof(int) * ((size_t)l + 1), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_rcol.p, h->rcol.data(), sizeof(int) * (size_t)h->nnz, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_cptr.p, h->cptr.data(), sizeof(int) * ((size_t)n + 1), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_crow.p, h->crow.data(), sizeof(int) * (size_t)h->nnz, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->db.p, h->b.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+        HIPCHK(hipMemset(h->part.p, 0, sizeof(double) * (size_t)BIG_NPART * h->G));
+        HIPCHK(hipMemset(h->red.p, 0, sizeof(double) * BIG_NPART));
+        h->uploaded = true;
+    }
+    HIPCHK(hipMemcpyAsync(h->df.p, h->f.data(), sizeof(double) * (size_t)h->l, hipMemcpyHostToDevice, h->stream));
+    const BigDev d = h->dev();
+    h->parity = 0;
+    HIPCHK(big_launch_init(d, std::pow((double)h->n_glob, 1.0 / 2), h->stream));   // pow(n, 1/p), p = 2 (LPcpp:427,503), n = ALL variables
+    CHK(allreduce(h, d.red, 1));
+    HIPCHK(big_launch_init2(d, h->stream));
+    ROWS(0);                                                                        // E * x0 for the first y3 (:720)
+    HIPCHK(big_launch_z4(d, 1, &h->parity, h->stream));
+    CHK(read_state(h));
+    h->inited = true;
+    return 1;
+}
+
+int lpbox_big_iterate(lpbox_big_t *h, int iter_start, int iter_end, int *ret) {     // ADMM_lp_iters LPcpp:766-1095
+    if (!h) return lpbox_fail(LPBOX_E_BADHANDLE, "bad handle");
+    if (!h->inited) return lpbox_fail(LPBOX_E_STATE, "solve_init has not been called");
+    CHK(use_device(h));
+    const BigDev d = h->dev();
+    HIPCHK(big_launch_set_window(d, iter_start, iter_end, &h->parity, h->stream));
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    for (;;) {
+        CHK(read_state(h));
+        if (h->hst.halt == BIG_HALT_PCG_MORE) {
+            HIPCHK(big_launch_resume(d, 0, &h->parity, h->stream));
+            CHK(enqueue_pcg(h, d, 16));
+            CHK(enqueue_tail(h, d));
+            if (h->adaptive) h->kmax = std::max(h->kmax, h->hst.pcg_k + 8);
+            continue;
+        }
+        if (h->hst.halt != BIG_HALT_NONE) break;
+        const int remaining = iter_end - h->hst.iter;
+        if (remaining <= 0 && !h->hst.have_prev) break;
+        if (h->adaptive && h->hst.outer_total > 0) h->kmax = std::max(4, h->hst.pcg_max + 3);
+        HIPCHK(big_launch_resume(d, 1, &h->parity, h->stream));
+        const int batch = std::min(std::max(remaining, 0), 16);
+        for (int it = 0; it < batch; it++) CHK(enqueue_iteration(h, d));
+        HIPCHK(big_launch_prep(d, 0, &h->parity, h->stream)); h->launches++;          // finalise the last iteration of the batch
+    }
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    h->kernel_ms += ms;
+    if (ret) *ret = h->hst.ret;
+    return LPBOX_OK;
+}
+
+int lpbox_big_get_x(lpbox_big_t *h, double *out_local) {
+    if (!h || !h->inited || !out_local) return lpbox_fail(LPBOX_E_STATE, "not initialised");
+    CHK(use_device(h));
+    HIPCHK(hipMemcpy(out_local, h->x.p, sizeof(double) * (size_t)h->n_loc, hipMemcpyDeviceToHost));
+    return h->n_loc;
+}
+
+int lpbox_big_get_vec(lpbox_big_t *h, const char *name, double *out, long cap) {
+    if (!h || !h->inited || !out || !name) return lpbox_fail(LPBOX_E_STATE, "not initialised");
+    CHK(use_device(h));
+    const double *src = nullptr; long len = h->n_loc;
+    if (!strcmp(name, "x")) src = h->x.p; else if (!strcmp(name, "z1")) src = h->z1.p; else if (!strcmp(name, "z2")) src = h->z2.p;
+    else if (!strcmp(name, "pd")) src = h->pd.p;
+    else if (!strcmp(name, "z4")) { src = h->z4.p; len = h->l; } else if (!strcmp(name, "Ex")) { src = h->Ex.p; len = h->l; }
+    else return lpbox_fail(LPBOX_E_BADARG, "unknown vector '%s'", name);
+    if (cap < len) return lpbox_fail(LPBOX_E_BADARG, "buffer too small");
+    HIPCHK(hipMemcpy(out, src, sizeof(double) * (size_t)len, hipMemcpyDeviceToHost));
+    return (int)len;
+}
+
+int lpbox_big_get_scalar(lpbox_big_t *h, const char *name, double *out) {
+    if (!h || !h->inited || !out || !name) return lpbox_fail(LPBOX_E_STATE, "not initialised");
+    const BigState &s = h->hst;
+    struct { const char *n; double v; } tab[] = {
+        {"rho1", s.rho1}, {"rho4", s.rho4}, {"gamma", s.gamma_val}, {"dI", s.dI}, {"rho4Et", s.r4Et}, {"std_obj", s.std_obj},
+        {"cur_obj", s.cur_obj}, {"best_bin_obj", s.best_bin_obj}, {"cvg1", s.cvg1}, {"cvg2", s.cvg2}, {"obj_val", s.obj_val},
+        {"iter", (double)s.iter}, {"outer_total", (double)s.outer_total}, {"pcg_total", (double)s.pcg_total}, {"last_pcg", (double)s.last_pcg},
+        {"stop", (double)s.stop}, {"plain_iter_p1", (double)s.plain_iter_p1}, {"kmax", (double)h->kmax},
+        {"launches", (double)h->launches}, {"collectives", (double)h->collectives}, {"kernel_ms", h->kernel_ms},
+        {"threads", (double)BIG_T}, {"chunk", (double)(BIG_T * h->EPT)}, {"groups", (double)h->G},
+    };
+    for (auto &e : tab) if (!strcmp(e.n, name)) { *out = e.v; return LPBOX_OK; }
+    return lpbox_fail(LPBOX_E_BADARG, "unknown scalar '%s'", name);
+}
+
+}  // extern "C"

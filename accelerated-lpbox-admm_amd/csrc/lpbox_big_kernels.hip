@@ -1,0 +1,478 @@
+// lpbox_big_kernels.hip -- gfx950 kernels of the LARGE-instance LP path (one LP, n up to ~1e6, variable-sharded).
+// Same arithmetic as lp_window_kernel (LPcpp:766-1095, ADMM_lp_iters), cut into kernels at the grid-wide dependencies:
+//   prep -> [fin] -> y -> rhs_cols -> rows -> [AR q] -> resid -> [fin] ->
+//   K x { rows(p) -> [AR q] -> pcg_cols -> [fin] -> pcg_upd -> [fin] } -> post -> [fin] -> rows(x) -> [AR q] -> z4
+// ([fin] = reduce the workgroup partials to red[]; on more than one rank the host all-reduces red[] / q after it.)
+// The PCG search direction p = z + beta p is recomputed on the fly for the gathered columns inside rows(p) (bit-identical
+// expression), so a PCG iteration needs no separate p-update launch.  Rows and columns are summed by one lane in ascending
+// index order; no FMA contraction; IEEE divide / sqrt.
+#include "lpbox_big.h"
+#include "lpbox_dev_common.h"
+
+#include <float.h>
+
+namespace {
+
+constexpr int T = BIG_T;
+#define LEADER (blockIdx.x == 0 && threadIdx.x == 0)
+
+__device__ __forceinline__ void forward_state(const BigDev &d, int in, int out) {
+    if (LEADER) d.st[out] = d.st[in];
+}
+
+template <int NV>
+__device__ __forceinline__ void store_partials(const BigDev &d, double (&v)[NV], double *red, int &parity) {
+    block_sum<T, NV>(v, red, parity);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; k++) d.part[(size_t)k * d.G + blockIdx.x] = v[k];
+    }
+}
+
+// red[v] = tree over the G workgroup partials of value v (second level of the fixed reduction order)
+__global__ void __launch_bounds__(T) big_k_fin(BigDev d, int nv) {
+    __shared__ double red[2 * RED_MAXV * RED_MAXW];
+    int parity = 0;
+    for (int v = 0; v < nv; v++) {
+        const double *p = d.part + (size_t)v * d.G;
+        double a[1] = {0.0};
+        for (int e = threadIdx.x; e < d.G; e += T) a[0] = a[0] + p[e];
+        block_sum<T, 1>(a, red, parity);
+        if (threadIdx.x == 0) d.red[v] = a[0];
+    }
+}
+
+__global__ void __launch_bounds__(T) big_k_init(BigDev d, double c1) {          // ADMM_lp_iters_init LPcpp:489-763
+    __shared__ double red[2 * RED_MAXV * RED_MAXW];
+    int parity = 0;
+    double pb[1] = {0.0};
+    for (int s = 0; s < d.EPT; s++) {
+        const int j = blockIdx.x * (T * d.EPT) + s * T + threadIdx.x;
+        double c = 0.0;
+        if (j < d.n_loc) {
+            d.x[j] = 1.0; d.z1[j] = 0.0; d.z2[j] = 0.0; d.pd[j] = 0.0; d.dinv[j] = 1.0;   // :583-586, :616-617
+            d.y1[j] = 1.0; d.y2[j] = 1.0; d.gsrc[j] = 1.0;
+            d.r[j] = 0.0; d.z[j] = 0.0; d.tmp[j] = 0.0; d.p0[j] = 0.0; d.p1[j] = 0.0; d.rhs[j] = 0.0;
+            c = d.b[j] * 1.0;                                                    // best_bin_obj = b.dot(x0) (:727)
+        }
+        pb[0] = pb[0] + c;
+    }
+    if (blockIdx.x < d.G) store_partials<1>(d, pb, red, parity);
+    for (int s = 0; s < d.EPTl; s++) {
+        const int i = blockIdx.x * (T * d.EPTl) + s * T + threadIdx.x;
+        if (i < d.l) { d.z4[i] = 0.0; d.y3[i] = 0.0; d.fy[i] = 0.0; d.Ex[i] = 0.0; }   // :650
+    }
+    if (LEADER) {
+        BigState *s = d.st;
+        memset(s, 0, sizeof(BigState));
+        s->rho1 = s->rho2 = s->rho4 = s->prev_rho1 = s->prev_rho2 = s->prev_rho4 = LP_RHO0;   // :623-630
+        s->gamma_val = LP_GAMMA0; s->std_obj = 1.0; s->rhoUpdated = 1; s->c1 = c1;
+        d.st[1] = d.st[0];
+    }
+}
+
+__global__ void big_k_init2(BigDev d) {       // after the partial of b.x0 has been reduced: best_bin_obj (:727)
+    d.st[0].best_bin_obj = d.red[0];
+    d.st[1].best_bin_obj = d.red[0];
+}
+
+__global__ void big_k_set_window(BigDev d, int in, int out, int iter_start, int iter_end) {
+    d.st[out] = d.st[in];
+    BigState *s = d.st + out;
+    s->iter = iter_start; s->iter_start = iter_start; s->iter_end = iter_end; s->ret = 0; s->stop = LP_STOP_NONE; s->halt = BIG_HALT_NONE;
+}
+
+__global__ void big_k_resume(BigDev d, int in, int out, int reset_pcg_max) {
+    d.st[out] = d.st[in];
+    if (d.st[out].halt == BIG_HALT_PCG_MORE) d.st[out].halt = BIG_HALT_NONE;
+    if (reset_pcg_max) d.st[out].pcg_max = 0;
+}
+
+// finalise the previous iteration from red[0..5) (x.x, |x-y1|^2, |x-y2|^2, b.x, b.round(x)), then partial ||x+z2/rho2-1/2||^2
+__global__ void __launch_bounds__(T) big_k_prep(BigDev d, int in, int out, int do_prep) {
+    __shared__ double red[2 * RED_MAXV * RED_MAXW];
+    int parity = 0;
+    const BigState *si = d.st + in;
+    const int halt0 = si->halt, have_prev = si->have_prev, it = si->iter, iter_end = si->iter_end;
+    double rho2 = si->rho2;
+    const bool fin = !halt0 && have_prev;
+    if (fin && (it + 1) % LP_RHO_STEP == 0) rho2 = LP_LEARNING_FACT * rho2;
+    const int next_iter = fin ? it + 1 : it;
+    const bool will_prep = do_prep && !halt0 && next_iter < iter_end;
+    if (LEADER) {
+        d.st[out] = *si;
+        BigState *s = d.st + out;
+        if (fin) {
+            s->have_prev = 0;
+            const double xn = sqrt(d.red[0]);
+            const double t0 = (xn < 2.2204e-16) ? 2.2204e-16 : xn;
+            s->cvg1 = sqrt(d.red[1]) / t0; s->cvg2 = sqrt(d.red[2]) / t0;      // :931-933
+            bool stopped = false;
+            if (s->cvg1 <= LP_STOP_THRESHOLD && s->cvg2 <= LP_STOP_THRESHOLD && it != s->iter_start) {   // :934 (plain loop: ret stays 0)
+                s->stop = LP_STOP_Y1Y2; stopped = true;
+            } else {
+                if ((it + 1) % LP_RHO_STEP == 0) {                                // :951-970
+                    s->prev_rho1 = s->rho1; s->prev_rho2 = s->rho2; s->prev_rho4 = s->rho4;
+                    s->rho1 = LP_LEARNING_FACT * s->rho1; s->rho2 = LP_LEARNING_FACT * s->rho2; s->rho4 = LP_LEARNING_FACT * s->rho4;
+                    const double g = s->gamma_val * LP_GAMMA_FACTOR;
+                    s->gamma_val = g < 1.0 ? 1.0 : g;
+                    s->rhoUpdated = 1; s->rcr = LP_LEARNING_FACT - 1.0;
+                }
+                s->obj_val = d.red[3];                                            // :972
+                int hn = s->hist_n;
+                if (hn < LP_HIST) s->hist[hn] = s->obj_val;
+                else { for (int k = 0; k < LP_HIST - 1; k++) s->hist[k] = s->hist[k + 1]; s->hist[LP_HIST - 1] = s->obj_val; }
+                if (hn < 0x3fffffff) hn++;
+                s->hist_n = hn;
+                if (hn >= LP_HIST) {                                              // :459-469, :358-377
+                    double mean = 0;
+                    for (int k = 0; k < LP_HIST; k++) mean += s->hist[k];
+                    mean /= (double)LP_HIST;
+                    double dev = 0;
+                    for (int k = 0; k < LP_HIST; k++) dev += (s->hist[k] - mean) * (s->hist[k] - mean);
+                    dev /= (double)(LP_HIST - 1);
+                    const double sd = (dev == 0) ? 0.0 : sqrt(dev);
+                    s->std_obj = sd / fabs(s->hist[LP_HIST - 1]);
+                }
+                if (s->std_obj <= LP_STD_THRESHOLD) { s->ret = 1; s->stop = LP_STOP_OBJSTD; stopped = true; }   // :977
+                else {
+                    s->cur_obj = d.red[4];                                        // :1001-1003
+                    if (s->best_bin_obj >= s->cur_obj) s->best_bin_obj = s->cur_obj;
+                }
+            }
+            if (stopped) { s->halt = BIG_HALT_STOP; s->plain_iter_p1 = it + 1; }
+            else s->iter = it + 1;
+        }
+        if (!s->halt && s->iter >= s->iter_end) { s->halt = BIG_HALT_WINDOW; s->plain_iter_p1 = s->iter + 1; }
+        if (!s->halt && do_prep) s->phase = 1;
+    }
+    if (!will_prep || blockIdx.x >= d.G) return;
+    double pa[1] = {0.0};
+    for (int q = 0; q < d.EPT; q++) {
+        const int j = blockIdx.x * (T * d.EPT) + q * T + threadIdx.x;
+        double c = 0.0;
+        if (j < d.n_loc) { const double u = (d.x[j] + d.z2[j] / rho2) - 0.5; c = u * u; }
+        pa[0] = pa[0] + c;
+    }
+    store_partials<1>(d, pa, red, parity);
+}
+
+// y1, y2, expression refresh (:831-866), rhs base, PCG start x0 = y1; for the rows: y3 = max(0, f - Ex - z4/rho4), fy = f - y3
+__global__ void __launch_bounds__(T) big_k_y(BigDev d, int in, int out) {
+    const BigState *si = d.st + in;
+    if (si->halt || si->phase != 1) { forward_state(d, in, out); return; }
+    const double rho1 = si->rho1, rho2 = si->rho2, rho4 = si->rho4, c1 = si->c1;
+    const int it = si->iter, rhoUpdated = si->rhoUpdated;
+    double dI = si->dI, r4Et = si->r4Et;
+    const bool first = it == 0, refresh = it != 0 && rhoUpdated;
+    const double inc = si->rcr * (si->prev_rho1 + si->prev_rho2), inc4 = si->rcr * si->prev_rho4;
+    if (first) { dI = 0.0; dI += rho1 + rho2; r4Et = rho4; }                     // update_expression(0) :2289-2404
+    if (refresh) { dI += inc; r4Et = LP_LEARNING_FACT * r4Et; }                  // :851-866
+    const double c2 = 2 * sqrt(d.red[0]);
+    if (blockIdx.x < d.G)
+        for (int q = 0; q < d.EPT; q++) {
+            const int j = blockIdx.x * (T * d.EPT) + q * T + threadIdx.x;
+            if (j >= d.n_loc) continue;
+            const double x = d.x[j], z1 = d.z1[j], z2 = d.z2[j];
+            const double t = x + z1 / rho1;
+            const double y1 = t > 1 ? 1 : (t < 0 ? 0 : t);                       // :806-809
+            double y2 = (x + z2 / rho2) - 0.5;                                   // :815-818
+            y2 = y2 * c1 / c2 + 0.5;
+            d.y1[j] = y1; d.y2[j] = y2;
+            double pd = d.pd[j];
+            const double Esq = (double)(d.cptr[j + 1] - d.cptr[j]);
+            if (first) { pd = dI; pd += rho4 * Esq; }
+            if (refresh) { pd += inc; pd += inc4 * Esq; }
+            d.pd[j] = pd;
+            if (rhoUpdated) d.dinv[j] = (pd != 0.0) ? 1.0 / pd : 1.0;            // :883-890
+            d.rhs[j] = (rho1 * y1 + rho2 * y2) - ((d.b[j] + z1) + z2);            // :872
+            d.gsrc[j] = y1;                                                       // x_sol = y1 (:892)
+        }
+    if (blockIdx.x < d.Gl)
+        for (int q = 0; q < d.EPTl; q++) {
+            const int i = blockIdx.x * (T * d.EPTl) + q * T + threadIdx.x;
+            if (i >= d.l) continue;
+            const double f = d.f[i];
+            const double v = f - d.Ex[i] - d.z4[i] / rho4;                        // :824-828
+            const double y3 = v < 0 ? 0 : v;
+            d.y3[i] = y3; d.fy[i] = f - y3;
+        }
+    if (LEADER) {
+        d.st[out] = *si;
+        BigState *s = d.st + out;
+        s->dI = dI; s->r4Et = r4Et; s->rhoUpdated = 0; s->expr_ready = 1;
+    }
+}
+
+__global__ void __launch_bounds__(T) big_k_rhs_cols(BigDev d, int in, int out) {   // :874-877
+    const BigState *si = d.st + in;
+    if (si->halt || si->phase != 1) { forward_state(d, in, out); return; }
+    const double r4Et = si->r4Et;
+    for (int q = 0; q < d.EPT; q++) {
+        const int j = blockIdx.x * (T * d.EPT) + q * T + threadIdx.x;
+        if (j >= d.n_loc) continue;
+        double tA = 0.0, tB = 0.0;
+        const int k1 = d.cptr[j + 1];
+        for (int k = d.cptr[j]; k < k1; k++) { const int i = d.crow[k]; tA += r4Et * d.fy[i]; tB += d.z4[i]; }
+        double r_ = d.rhs[j];
+        r_ += tA;
+        r_ -= tB;
+        d.rhs[j] = r_;
+    }
+    forward_state(d, in, out);
+}
+
+// q_part = E[:, shard] * v over this rank's columns.  mode 0: v = gsrc.  mode 1: v = the PCG search direction, with the exit
+// test / beta of the previous PCG iteration evaluated here (LPcpp:296-319).
+__global__ void __launch_bounds__(T) big_k_rows(BigDev d, int in, int out, int mode) {
+    const BigState *si = d.st + in;
+    if (si->halt) { forward_state(d, in, out); return; }
+    double beta = 0.0;
+    bool first = false;
+    const double *pold = nullptr;
+    if (mode == 1) {
+        if (si->phase != 2 || si->pcg_done) { forward_state(d, in, out); return; }
+        const int k = si->pcg_k;
+        double threshold = si->threshold, absNew = si->absNew, rhsNorm2 = si->rhsNorm2;
+        bool done = false; int zero_x = 0;
+        first = k == 0;
+        if (first) {
+            rhsNorm2 = d.red[0];
+            if (rhsNorm2 == 0) { done = true; zero_x = 1; }                      // :273-278
+            else {
+                double thr = LP_PCG_TOL * LP_PCG_TOL * rhsNorm2;                 // :281
+                if (thr < DBL_MIN) thr = DBL_MIN;
+                threshold = thr;
+                if (d.red[1] < thr) done = true;                                 // :284
+                absNew = d.red[2];
+            }
+        } else {
+            if (d.red[0] < threshold || k >= LP_PCG_MAXITERS) done = true;       // :309-312, :296
+            else { const double absOld = absNew; absNew = d.red[1]; beta = absNew / absOld; }   // :316-318
+        }
+        if (LEADER) {
+            d.st[out] = *si;
+            BigState *s = d.st + out;
+            s->threshold = threshold; s->absNew = absNew; s->rhsNorm2 = rhsNorm2; s->beta = beta;
+            s->pcg_done = done ? 1 : 0; s->pcg_first = zero_x;
+        }
+        if (done) return;
+        pold = ((k - 1) & 1) ? d.p1 : d.p0;
+    } else forward_state(d, in, out);
+    const double *gs = d.gsrc, *zz = d.z, *p0 = d.p0;
+    for (int s = 0; s < d.EPTl; s++) {
+        const int i = blockIdx.x * (T * d.EPTl) + s * T + threadIdx.x;
+        if (i >= d.l) continue;
+        double acc = 0.0;
+        const int k1 = d.rptr[i + 1];
+        if (mode == 0) for (int k = d.rptr[i]; k < k1; k++) acc += gs[d.rcol[k]];
+        else if (first) for (int k = d.rptr[i]; k < k1; k++) acc += p0[d.rcol[k]];
+        else for (int k = d.rptr[i]; k < k1; k++) { const int c = d.rcol[k]; acc += zz[c] + beta * pold[c]; }
+        d.q[i] = acc;
+    }
+}
+
+__global__ void __launch_bounds__(T) big_k_resid(BigDev d, int in, int out) {       // :267-294
+    __shared__ double red[2 * RED_MAXV * RED_MAXW];
+    int parity = 0;
+    const BigState *si = d.st + in;
+    if (si->halt || si->phase != 1) { forward_state(d, in, out); return; }
+    const double dI = si->dI, r4Et = si->r4Et;
+    double pb[3] = {0.0, 0.0, 0.0};
+    for (int q = 0; q < d.EPT; q++) {
+        const int j = blockIdx.x * (T * d.EPT) + q * T + threadIdx.x;
+        double c0 = 0.0, c1 = 0.0, c2 = 0.0;
+        if (j < d.n_loc) {
+            double t = 0.0;
+            const int k1 = d.cptr[j + 1];
+            for (int k = d.cptr[j]; k < k1; k++) t += r4Et * d.q[d.crow[k]];
+            const double y1 = d.y1[j];
+            double Mx = 0.0;
+            Mx += dI * (1.0 * y1);
+            Mx += t;
+            const double rhs = d.rhs[j];
+            const double r = rhs - Mx;
+            const double p = d.dinv[j] * r;
+            d.x[j] = y1; d.r[j] = r; d.p0[j] = p;
+            c0 = rhs * rhs; c1 = r * r; c2 = r * p;
+        }
+        pb[0] = pb[0] + c0; pb[1] = pb[1] + c1; pb[2] = pb[2] + c2;
+    }
+    store_partials<3>(d, pb, red, parity);
+    if (LEADER) { d.st[out] = *si; d.st[out].pcg_k = 0; d.st[out].pcg_done = 0; d.st[out].pcg_first = 0; d.st[out].phase = 2; }
+}
+
+__global__ void __launch_bounds__(T) big_k_pcg_cols(BigDev d, int in, int out) {    // tmp = M p, partial p.tmp (:298-300)
+    __shared__ double red[2 * RED_MAXV * RED_MAXW];
+    int parity = 0;
+    const BigState *si = d.st + in;
+    if (si->halt || si->phase != 2) { forward_state(d, in, out); return; }
+    if (si->pcg_done) {
+        if (si->pcg_first)                                                       // rhs == 0: x := 0 (:273-278)
+            for (int q = 0; q < d.EPT; q++) { const int j = blockIdx.x * (T * d.EPT) + q * T + threadIdx.x; if (j < d.n_loc) d.x[j] = 0.0; }
+        if (LEADER) { d.st[out] = *si; d.st[out].pcg_first = 0; }
+        return;
+    }
+    const int k = si->pcg_k;
+    const double dI = si->dI, r4Et = si->r4Et, beta = si->beta;
+    const bool first = k == 0;
+    const double *pold = ((k - 1) & 1) ? d.p1 : d.p0;
+    double *pnew = (k & 1) ? d.p1 : d.p0;
+    double pc[1] = {0.0};
+    for (int q = 0; q < d.EPT; q++) {
+        const int j = blockIdx.x * (T * d.EPT) + q * T + threadIdx.x;
+        double c = 0.0;
+        if (j < d.n_loc) {
+            double pj;
+            if (first) pj = d.p0[j];
+            else { pj = d.z[j] + beta * pold[j]; pnew[j] = pj; }                  // p = z + beta p (:319)
+            double t = 0.0;
+            const int k1 = d.cptr[j + 1];
+            for (int kk = d.cptr[j]; kk < k1; kk++) t += r4Et * d.q[d.crow[kk]];
+            double Mp = 0.0;
+            Mp += dI * (1.0 * pj);
+            Mp += t;
+            d.tmp[j] = Mp;
+            c = pj * Mp;
+        }
+        pc[0] = pc[0] + c;
+    }
+    store_partials<1>(d, pc, red, parity);
+    forward_state(d, in, out);
+}
+
+__global__ void __launch_bounds__(T) big_k_pcg_upd(BigDev d, int in, int out) {     // :300-317
+    __shared__ double red[2 * RED_MAXV * RED_MAXW];
+    int parity = 0;
+    const BigState *si = d.st + in;
+    if (si->halt || si->phase != 2 || si->pcg_done) { forward_state(d, in, out); return; }
+    const int k = si->pcg_k;
+    const double alpha = si->absNew / d.red[0];
+    // (alpha < 0 -> the plain loop ignores the PCG's -1 return, LPcpp:894; x keeps the updates made so far, which is what
+    //  happens here too because the remaining pairs fall through once pcg_done is set)
+    const bool fail = alpha < 0;
+    const double *p = (k & 1) ? d.p1 : d.p0;
+    double pd2[2] = {0.0, 0.0};
+    if (!fail)
+        for (int q = 0; q < d.EPT; q++) {
+            const int j = blockIdx.x * (T * d.EPT) + q * T + threadIdx.x;
+            double a = 0.0, b2 = 0.0;
+            if (j < d.n_loc) {
+                double x = d.x[j], r = d.r[j];
+                x += alpha * p[j];
+                r -= alpha * d.tmp[j];
+                const double z = d.dinv[j] * r;
+                d.x[j] = x; d.r[j] = r; d.z[j] = z;
+                a = r * r; b2 = r * z;
+            }
+            pd2[0] = pd2[0] + a; pd2[1] = pd2[1] + b2;
+        }
+    if (!fail) store_partials<2>(d, pd2, red, parity);
+    if (LEADER) {
+        d.st[out] = *si;
+        if (fail) { d.st[out].pcg_done = 1; d.st[out].stop = LP_STOP_PCG; }
+        else d.st[out].pcg_k = k + 1;
+    }
+}
+
+// after the PCG: duals z1, z2 (:917-918), the five partials (:931-1003), gsrc = x for the E*x that feeds z4 and the next y3
+__global__ void __launch_bounds__(T) big_k_post(BigDev d, int in, int out) {
+    __shared__ double red[2 * RED_MAXV * RED_MAXW];
+    int parity = 0;
+    const BigState *si = d.st + in;
+    if (si->halt || si->phase != 2) { forward_state(d, in, out); return; }
+    const int k = si->pcg_k;
+    if (!si->pcg_done) {                      // the exit test of the last update is still pending
+        if (!(k >= 1 && (d.red[0] < si->threshold || k >= LP_PCG_MAXITERS))) {
+            if (LEADER) { d.st[out] = *si; d.st[out].halt = BIG_HALT_PCG_MORE; }
+            return;
+        }
+    }
+    const double g1 = si->gamma_val * si->rho1, g2 = si->gamma_val * si->rho2;
+    double e5[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int q = 0; q < d.EPT; q++) {
+        const int j = blockIdx.x * (T * d.EPT) + q * T + threadIdx.x;
+        double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0, v4 = 0.0;
+        if (j < d.n_loc) {
+            const double x = d.x[j], y1 = d.y1[j], y2 = d.y2[j], b = d.b[j];
+            d.z1[j] = d.z1[j] + g1 * (x - y1);
+            d.z2[j] = d.z2[j] + g2 * (x - y2);
+            d.gsrc[j] = x;
+            const double d1 = x - y1, d2 = x - y2, xb = x >= 0.5 ? 1.0 : 0.0;
+            v0 = x * x; v1 = d1 * d1; v2 = d2 * d2; v3 = b * x; v4 = b * xb;
+        }
+        e5[0] = e5[0] + v0; e5[1] = e5[1] + v1; e5[2] = e5[2] + v2; e5[3] = e5[3] + v3; e5[4] = e5[4] + v4;
+    }
+    store_partials<5>(d, e5, red, parity);
+    if (LEADER) {
+        d.st[out] = *si;
+        BigState *s = d.st + out;
+        s->pcg_done = 1; s->last_pcg = k; s->pcg_total += k; s->outer_total++;
+        if (k > s->pcg_max) s->pcg_max = k;
+        s->phase = 3;
+    }
+}
+
+// Ex = q (= E*x, already all-reduced), z4 dual update (:919-924; the plain loop OVERWRITES z4 on the first iteration of a call)
+__global__ void __launch_bounds__(T) big_k_z4(BigDev d, int in, int out, int init_only) {
+    const BigState *si = d.st + in;
+    if (init_only) {
+        for (int s = 0; s < d.EPTl; s++) { const int i = blockIdx.x * (T * d.EPTl) + s * T + threadIdx.x; if (i < d.l) d.Ex[i] = d.q[i]; }
+        forward_state(d, in, out);
+        return;
+    }
+    if (si->halt || si->phase != 3) { forward_state(d, in, out); return; }
+    const double g4 = si->gamma_val * si->rho4;
+    const bool overwrite = si->iter == si->iter_start;
+    for (int s = 0; s < d.EPTl; s++) {
+        const int i = blockIdx.x * (T * d.EPTl) + s * T + threadIdx.x;
+        if (i >= d.l) continue;
+        const double Ex = d.q[i];
+        d.Ex[i] = Ex;
+        const double dd = g4 * ((Ex + d.y3[i]) - d.f[i]);
+        d.z4[i] = overwrite ? dd : d.z4[i] + dd;
+    }
+    if (LEADER) { d.st[out] = *si; d.st[out].have_prev = 1; d.st[out].phase = 0; }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------
+#define BIG_LAUNCH(kernel, grid, ...)                                                                     \
+    do {                                                                                                  \
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(T), 0, s, d, *parity, *parity ^ 1, ##__VA_ARGS__);    \
+        *parity ^= 1;                                                                                     \
+    } while (0)
+
+hipError_t big_launch_init(const BigDev &d, double c1, hipStream_t s) {
+    hipLaunchKernelGGL(big_k_init, dim3(d.G > d.Gl ? d.G : d.Gl), dim3(T), 0, s, d, c1);
+    hipLaunchKernelGGL(big_k_fin, dim3(1), dim3(T), 0, s, d, 1);
+    return hipGetLastError();
+}
+hipError_t big_launch_init2(const BigDev &d, hipStream_t s) {
+    hipLaunchKernelGGL(big_k_init2, dim3(1), dim3(1), 0, s, d);
+    return hipGetLastError();
+}
+hipError_t big_launch_set_window(const BigDev &d, int iter_start, int iter_end, int *parity, hipStream_t s) {
+    hipLaunchKernelGGL(big_k_set_window, dim3(1), dim3(1), 0, s, d, *parity, *parity ^ 1, iter_start, iter_end);
+    *parity ^= 1;
+    return hipGetLastError();
+}
+hipError_t big_launch_resume(const BigDev &d, int reset_pcg_max, int *parity, hipStream_t s) {
+    hipLaunchKernelGGL(big_k_resume, dim3(1), dim3(1), 0, s, d, *parity, *parity ^ 1, reset_pcg_max);
+    *parity ^= 1;
+    return hipGetLastError();
+}
+hipError_t big_launch_prep(const BigDev &d, int do_prep, int *parity, hipStream_t s) { BIG_LAUNCH(big_k_prep, d.G, do_prep); return hipGetLastError(); }
+hipError_t big_launch_fin(const BigDev &d, int nv, hipStream_t s) {
+    hipLaunchKernelGGL(big_k_fin, dim3(1), dim3(T), 0, s, d, nv);
+    return hipGetLastError();
+}
+hipError_t big_launch_y(const BigDev &d, int *parity, hipStream_t s) { BIG_LAUNCH(big_k_y, (d.G > d.Gl ? d.G : d.Gl)); return hipGetLastError(); }
+hipError_t big_launch_rhs_cols(const BigDev &d, int *parity, hipStream_t s) { BIG_LAUNCH(big_k_rhs_cols, d.G); return hipGetLastError(); }
+hipError_t big_launch_rows(const BigDev &d, int mode, int *parity, hipStream_t s) { BIG_LAUNCH(big_k_rows, d.Gl, mode); return hipGetLastError(); }
+hipError_t big_launch_resid(const BigDev &d, int *parity, hipStream_t s) { BIG_LAUNCH(big_k_resid, d.G); return hipGetLastError(); }
+hipError_t big_launch_pcg_cols(const BigDev &d, int *parity, hipStream_t s) { BIG_LAUNCH(big_k_pcg_cols, d.G); return hipGetLastError(); }
+hipError_t big_launch_pcg_upd(const BigDev &d, int *parity, hipStream_t s) { BIG_LAUNCH(big_k_pcg_upd, d.G); return hipGetLastError(); }
+hipError_t big_launch_post(const BigDev &d, int *parity, hipStream_t s) { BIG_LAUNCH(big_k_post, d.G); return hipGetLastError(); }
+hipError_t big_launch_z4(const BigDev &d, int init_only, int *parity, hipStream_t s) { BIG_LAUNCH(big_k_z4, d.Gl, init_only); return hipGetLastError(); }

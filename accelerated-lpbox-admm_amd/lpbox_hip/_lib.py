@@ -59,7 +59,20 @@ SYMBOLS = {
     "lpbox_kernel_time": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]),
     "lpbox_debug_get_vec": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, _dp, C.c_int]),
     "lpbox_debug_get_scalar": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.POINTER(C.c_double)]),
+    "lpbox_big_create": (C.c_void_p, [C.c_int, C.c_int, C.c_int]),
+    "lpbox_big_destroy": (None, [C.c_void_p]),
+    "lpbox_big_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "lpbox_big_set_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lpbox_big_set_exchange": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lpbox_big_set_problem": (C.c_int, [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, _ip, _ip, _dp, C.c_void_p]),
+    "lpbox_big_init": (C.c_int, [C.c_void_p]),
+    "lpbox_big_iterate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "lpbox_big_get_x": (C.c_int, [C.c_void_p, _dp]),
+    "lpbox_big_get_vec": (C.c_int, [C.c_void_p, C.c_char_p, _dp, C.c_long]),
+    "lpbox_big_get_scalar": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]),
 }
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_long, C.c_void_p)
 
 _lib = None
 

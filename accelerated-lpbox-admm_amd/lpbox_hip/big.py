@@ -1,0 +1,104 @@
+"""One large LP, variable-sharded over the ranks of a torch.distributed process group (BASELINE config 5).
+
+Every rank holds a contiguous block of columns of E and runs the large-instance kernels of liblpbox_hip.so on its GPU; the
+library calls back into `BigLp._allreduce` wherever the algorithm sums over all variables (E*v: an l-vector per PCG
+iteration; a handful of scalars per reduction), which is a `torch.distributed.all_reduce` (backend "nccl" = RCCL over xGMI;
+"gloo" through host staging for tests).  With world == 1 no collective is issued and torch is not needed.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check
+from .dist import shard_range
+
+
+class BigLp:
+    def __init__(self, problem, rank=0, world=1, device=0, use_torch_stream=None):
+        """problem: dict(n, l, colptr, rowidx, b[, f]) of the WHOLE instance (CSC, 0/1 pattern, b already negated)."""
+        self._L = _lib.load()
+        self.rank, self.world = int(rank), int(world)
+        n, l = int(problem["n"]), int(problem["l"])
+        self.n, self.l = n, l
+        self.c0, self.c1 = shard_range(n, world, rank)
+        cp = np.asarray(problem["colptr"], np.int64)
+        lo, hi = cp[self.c0], cp[self.c1]
+        colptr = np.ascontiguousarray(cp[self.c0:self.c1 + 1] - lo, np.int32)
+        rowidx = np.ascontiguousarray(np.asarray(problem["rowidx"])[lo:hi], np.int32)
+        b = np.ascontiguousarray(np.asarray(problem["b"], np.float64)[self.c0:self.c1])
+        f = problem.get("f")
+        h = self._L.lpbox_big_create(self.rank, self.world, int(device))
+        if not h:
+            check(-2, "lpbox_big_create")
+        self._h = C.c_void_p(h)
+        self._keep = []
+        if world > 1 or use_torch_stream:
+            import torch
+            torch.cuda.set_device(device)
+            self._q = torch.zeros(l, dtype=torch.float64, device="cuda")
+            self._red = torch.zeros(8, dtype=torch.float64, device="cuda")
+            check(self._L.lpbox_big_set_stream(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "lpbox_big_set_stream")
+            check(self._L.lpbox_big_set_exchange(self._h, C.c_void_p(self._q.data_ptr()), C.c_void_p(self._red.data_ptr())),
+                  "lpbox_big_set_exchange")
+            if world > 1:
+                self._cb = _lib.ALLREDUCE_FN(self._allreduce)
+                check(self._L.lpbox_big_set_allreduce(self._h, C.cast(self._cb, C.c_void_p), None), "lpbox_big_set_allreduce")
+        fp = None
+        if f is not None:
+            f = np.ascontiguousarray(f, np.float64)
+            fp = f.ctypes.data_as(C.c_void_p)
+        check(self._L.lpbox_big_set_problem(self._h, n, self.c0, self.c1 - self.c0, l, colptr, rowidx, b, fp), "lpbox_big_set_problem")
+
+    def _allreduce(self, ptr, count, user):
+        try:
+            import torch.distributed as dist
+            t = self._q if ptr == self._q.data_ptr() else self._red
+            v = t[:count]
+            if dist.get_backend() == "nccl":
+                dist.all_reduce(v)
+            else:                       # gloo (tests): stage through the host
+                c = v.cpu()
+                dist.all_reduce(c)
+                v.copy_(c)
+            return 0
+        except Exception as e:          # never let an exception cross the C boundary
+            print("lpbox big all-reduce failed:", e)
+            return 1
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.lpbox_big_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def solve_init(self):
+        return check(self._L.lpbox_big_init(self._h), "lpbox_big_init")
+
+    def solve_iter(self, i, j):
+        ret = C.c_int()
+        check(self._L.lpbox_big_iterate(self._h, int(i), int(j), C.byref(ret)), "lpbox_big_iterate")
+        return ret.value
+
+    def local_x(self):
+        out = np.zeros(self.c1 - self.c0)
+        check(self._L.lpbox_big_get_x(self._h, out), "lpbox_big_get_x")
+        return out
+
+    def vec(self, name):
+        out = np.zeros(max(self.c1 - self.c0, self.l))
+        k = check(self._L.lpbox_big_get_vec(self._h, name.encode(), out, len(out)), "lpbox_big_get_vec")
+        return out[:k].copy()
+
+    def scalar(self, name):
+        v = C.c_double()
+        check(self._L.lpbox_big_get_scalar(self._h, name.encode(), C.byref(v)), "lpbox_big_get_scalar")
+        return v.value
+
+    def cal_Obj(self):
+        return self.scalar("cur_obj")          # LPcpp:1630-1642 with nothing fixed: sum_fix_obj = 0

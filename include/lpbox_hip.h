@@ -129,6 +129,29 @@ int lpbox_kernel_time(lpbox_t *h, double *ms_total, long long *launches, int res
 int lpbox_debug_get_vec(lpbox_t *h, int idx, const char *name, double *out, int cap);
 int lpbox_debug_get_scalar(lpbox_t *h, int idx, const char *name, double *out);
 
+/* ---- LARGE single LP, variable-sharded over ranks (BASELINE config 5; no reference counterpart: the reference is one
+ * process).  Rank r holds the columns [c0, c0+n_loc) of E (all l rows), its slice of b, and the full f; the l-vectors are
+ * replicated.  Where the algorithm sums over all variables (E*v: an l-vector once per PCG iteration and twice per outer
+ * iteration; <= 5 scalars per reduction) the library calls `fn(dev_ptr, count, user)`, which must sum `count` doubles at
+ * dev_ptr in place over all ranks, stream-ordered on the stream given to lpbox_big_set_stream (RCCL all-reduce through
+ * torch.distributed in lpbox_hip/big.py).  world == 1 issues no collective.  Semantics: ADMM_lp_iters (LPcpp:766-1095). */
+typedef struct lpbox_big lpbox_big_t;
+typedef int (*lpbox_allreduce_fn)(void *dev_ptr, long count, void *user);
+lpbox_big_t *lpbox_big_create(int rank, int world, int device);
+void lpbox_big_destroy(lpbox_big_t *h);
+int lpbox_big_set_stream(lpbox_big_t *h, void *hip_stream);
+int lpbox_big_set_allreduce(lpbox_big_t *h, lpbox_allreduce_fn fn, void *user);
+/* optional caller-owned device buffers for the two exchanged quantities (l doubles for E*v, 8 doubles for the scalars), so that
+ * the all-reduce can run on the caller's own tensors (e.g. torch); call before lpbox_big_init */
+int lpbox_big_set_exchange(lpbox_big_t *h, void *q_dev, void *red_dev);
+int lpbox_big_set_problem(lpbox_big_t *h, long n_glob, int c0, int n_loc, int l, const int *colptr, const int *rowidx,
+                          const double *b, const double *f);
+int lpbox_big_init(lpbox_big_t *h);                                             /* ADMM_lp_iters_init LPcpp:489-763 */
+int lpbox_big_iterate(lpbox_big_t *h, int iter_start, int iter_end, int *ret);  /* ADMM_lp_iters      LPcpp:766-1095 */
+int lpbox_big_get_x(lpbox_big_t *h, double *out_local);                         /* this rank's slice of x_sol */
+int lpbox_big_get_vec(lpbox_big_t *h, const char *name, double *out, long cap); /* "x","z1","z2","pd" (local), "z4","Ex" (rows) */
+int lpbox_big_get_scalar(lpbox_big_t *h, const char *name, double *out);        /* "cur_obj","iter","stop","outer_total","pcg_total",... */
+
 #ifdef __cplusplus
 }
 #endif

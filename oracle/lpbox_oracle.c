@@ -174,6 +174,7 @@ struct lpo {
     double *full;                  /* scratch, org_n + padding, for the GPU reduction order */
     int *gpu_pos; int gpu_pos_n;   /* storage position of each original variable in the kernels (NULL = identity) */
     int gpu_npos;                  /* number of storage positions (>= org_n; holes contribute +0.0) */
+    int gpu_chunk;                 /* > 0: two-level order of the large-instance kernels (workgroup partials of `chunk` positions) */
     int *row_G;                    /* GPU order: lanes that share row i of E (1,2,4,8); NULL = 1 */
     int *orgEr_ptr, *orgEr_col; double *orgEr_val;   /* CSR view of org_E (rows in ascending column order) */
     double *full_v;                /* scratch: a live vector expanded to the original variable order */
@@ -245,6 +246,7 @@ void lpo_set_order(lpo_t *o, int mode, int T) {
 }
 
 void lpo_set_verbose(lpo_t *o, int verbose) { o->verbose = verbose; }
+void lpo_set_chunk(lpo_t *o, int chunk) { o->gpu_chunk = chunk > 0 ? chunk : 0; }
 
 void lpo_set_positions(lpo_t *o, const int *pos_of_var, int n, int npos) {
     free(o->gpu_pos);
@@ -331,6 +333,15 @@ static double reduce(lpo_t *o, const double *a, int cnt, const int *map) {
         for (int i = 0; i < cnt; i++) o->full[o->gpu_pos[map[i]]] = a[i];
     else
         for (int i = 0; i < cnt; i++) o->full[map[i]] = a[i];
+    if (o->gpu_chunk > 0) {        /* lpbox_big_kernels.hip: block tree per chunk, then the same tree over the chunk partials */
+        const int CH = o->gpu_chunk, Gn = (npos + CH - 1) / CH;
+        double *part = o->full + npos;
+        for (int g = 0; g < Gn; g++) {
+            int len = npos - g * CH; if (len > CH) len = CH;
+            part[g] = redux_sum_gpu_full(o->full + (size_t)g * CH, len, o->T);
+        }
+        return redux_sum_gpu_full(part, Gn, o->T);
+    }
     return redux_sum_gpu_full(o->full, npos, o->T);
 }
 

@@ -45,6 +45,9 @@ void lpo_set_order(lpo_t *o, int mode, int T);
 void lpo_set_positions(lpo_t *o, const int *pos_of_var, int n, int npos);
 /* GPU order only: lanes_of_row[i] in {1,2,4,8} lanes share the sum of row i of E (lpbox_get_row_split). */
 void lpo_set_row_split(lpo_t *o, const int *lanes_of_row, int l);
+/* GPU order of the LARGE-instance kernels: reductions are two-level (a block tree over every `chunk` consecutive positions, then
+ * the same tree over the chunk partials).  0 = single workgroup (default). */
+void lpo_set_chunk(lpo_t *o, int chunk);
 /* 1 = print the reference's stop messages to stdout (default 0 = quiet). */
 void lpo_set_verbose(lpo_t *o, int verbose);
 
