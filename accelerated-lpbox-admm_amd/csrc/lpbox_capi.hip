@@ -607,6 +607,7 @@ int lpbox_iterate_l2f(lpbox_t *h, int iter_start, int iter_end, const double *ve
         const LpInstance &I = h->inst[i];
         const int n_live = (int)I.left_idx.size();
         const int num = nums ? nums[i] : 0;
+        if (num != 0 && !h->h_isc[i * NI_COUNT + NI_ACTIVE]) return fail(LPBOX_E_BADARG, "instance %zu is parked (lpbox_set_active) but has a fix request", i);
         if (num < 0 || num > n_live) return fail(LPBOX_E_BADARG, "instance %zu: fix count %d outside [0,%d]", i, num, n_live);
         if (num != 0) {
             if (!vec) return fail(LPBOX_E_BADARG, "fix vector missing");
@@ -666,6 +667,18 @@ int lpbox_iterate_l2f(lpbox_t *h, int iter_start, int iter_end, const double *ve
     return h->h_isc[NI_RET];
 }
 
+int lpbox_set_active(lpbox_t *h, const int *active) {
+    if (!valid_handle(h) || h->seg) return fail(LPBOX_E_BADHANDLE, "bad handle (LP flavour only)");
+    if (!h->inited) return fail(LPBOX_E_STATE, "solve_init has not been called");
+    int rc = use_device(h);
+    if (rc) return rc;
+    std::vector<int> a(h->B, 1);
+    for (int i = 0; i < h->B && active; i++) a[i] = active[i] != 0;
+    HIPCHK(hipMemcpy2D(h->isc.p + NI_ACTIVE, NI_COUNT * sizeof(int), a.data(), sizeof(int), sizeof(int), h->B, hipMemcpyHostToDevice));
+    for (int i = 0; i < h->B; i++) h->h_isc[(size_t)i * NI_COUNT + NI_ACTIVE] = a[i];
+    return LPBOX_OK;
+}
+
 int lpbox_get_n(lpbox_t *h, int idx) {
     if (valid_handle(h) && h->seg) return segc_get_n(h->seg);
     int rc = check_idx(h, idx);
@@ -722,6 +735,24 @@ int lpbox_get_x_iters(lpbox_t *h, int idx, int ws, double *out) {
             for (int c = 0; c < ws; c++) out[(size_t)r * ws + c] = c < wsd ? tmp[(size_t)r * wsd + c] : 0.0;
     }
     return rows;
+}
+
+int lpbox_get_x_iters_device(lpbox_t *h, int ws, void **dev_ptr, long *stride_doubles) {
+    if (!valid_handle(h) || h->seg) return fail(LPBOX_E_BADHANDLE, "bad handle (LP flavour only)");
+    if (!h->xi_valid) return fail(LPBOX_E_STATE, "solve_iter_l2f has not been called");
+    if (ws <= 0 || ws > h->ws_cap) return fail(LPBOX_E_BADARG, "ws = %d outside (0,%d] (the last window)", ws, h->ws_cap);
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (h->xi_out_ws != ws) {
+        const long stride = (long)h->NS * ws;
+        if (h->xi_out.count < (size_t)h->B * stride) HIPCHK(h->xi_out.alloc((size_t)h->B * stride));
+        HIPCHK(lp_launch_pack_xiters(h->dev(), h->left_idx.p, h->xi_rows.p, ws, h->xi_out.p, stride, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->xi_out_ws = ws; h->xi_out_stride = stride;
+    }
+    if (dev_ptr) *dev_ptr = h->xi_out.p;
+    if (stride_doubles) *stride_doubles = h->xi_out_stride;
+    return LPBOX_OK;
 }
 
 int lpbox_get_x_sol(lpbox_t *h, int idx, double *out) {

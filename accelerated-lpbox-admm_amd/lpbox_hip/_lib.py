@@ -38,6 +38,8 @@ SYMBOLS = {
     "lpbox_get_l": (C.c_int, [C.c_void_p, C.c_int]),
     "lpbox_get_iter": (C.c_int, [C.c_void_p, C.c_int]),
     "lpbox_get_x_iters": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "lpbox_set_active": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "lpbox_get_x_iters_device": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_long)]),
     "lpbox_get_x_sol": (C.c_int, [C.c_void_p, C.c_int, _dp]),
     "lpbox_get_final_x_sol": (C.c_int, [C.c_void_p, C.c_int, _dp]),
     "lpbox_cal_obj": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
@@ -77,6 +79,24 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_long, C.c_void_p)
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One process must hold ONE HIP runtime.  PyTorch-ROCm wheels bundle their own libamdhip64 (SONAME libamdhip64.so.7);
+    if ours (from /opt/rocm) were mapped first, a later `import torch` would map a second copy and fail to see the GPU.
+    Mapping torch's copy first (without importing torch) makes both resolve to the same object, in either import order."""
+    if os.environ.get("LPBOX_SYSTEM_HIP") == "1":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:       # no torch / unusual layout: fall back to the system runtime named in the library's RUNPATH
+        pass
+
+
 def load():
     """Load the shared library once; raise ImportError (loudly) when it has not been built."""
     global _lib
@@ -86,6 +106,7 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `make -C accelerated-lpbox-admm_amd/csrc` "
             "(or __graft_entry__.build()). There is no CPU fallback.")
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol

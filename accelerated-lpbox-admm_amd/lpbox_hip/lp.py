@@ -108,6 +108,13 @@ class LpBatch:
                                         rets.ctypes.data_as(C.c_void_p)), "lpbox_iterate_l2f")
         return rets
 
+    def set_active(self, active=None):
+        """Park (False) / resume (True) instances of the batch; parked ones are skipped by solve_iter / solve_iter_l2f."""
+        a = None if active is None else np.ascontiguousarray(np.asarray(active) != 0, np.int32)
+        if a is not None and a.shape != (self.B,):
+            raise ValueError("active must have one entry per instance")
+        check(self._L.lpbox_set_active(self._h, None if a is None else a.ctypes.data_as(C.c_void_p)), "lpbox_set_active")
+
     # ---- results ----
     def get_n(self, idx=0):
         return check(self._L.lpbox_get_n(self._h, idx), "lpbox_get_n")
@@ -128,6 +135,17 @@ class LpBatch:
         if rows and ws:
             check(self._L.lpbox_get_x_iters(self._h, idx, ws, out.ctypes.data_as(C.c_void_p)), "lpbox_get_x_iters")
         return out
+
+    def x_iters_torch(self, ws):
+        """The (n_live_i x ws) iterate windows of the whole batch as ONE torch CUDA tensor view (zero copy): returns
+        (flat, stride) where instance i is flat[i*stride : i*stride + rows_i*ws].view(rows_i, ws)."""
+        import torch
+        ptr, stride = C.c_void_p(), C.c_long()
+        check(self._L.lpbox_get_x_iters_device(self._h, _as_int(ws, "ws"), C.byref(ptr), C.byref(stride)), "lpbox_get_x_iters_device")
+
+        class _Dev:     # the CUDA array interface is how torch adopts foreign device memory without copying
+            __cuda_array_interface__ = {"shape": (self.B * stride.value,), "typestr": "<f8", "data": (ptr.value, False), "version": 2}
+        return torch.as_tensor(_Dev(), device="cuda"), stride.value
 
     def get_x_sol(self, idx=0):
         out = np.zeros(self.get_org_n(idx), np.float64)

@@ -83,6 +83,14 @@ int lpbox_get_iter(lpbox_t *h, int idx);                      /* LP pxd:16 get_i
 /* LP pxd:14 `double* get_x_iters_d(int)` (LPcpp:1616-1627): out[rows*ws] row-major, rows = n_live of the last
  * l2f call; returns rows.  out may be NULL to query rows. */
 int lpbox_get_x_iters(lpbox_t *h, int idx, int ws, double *out);
+/* Batched use only: park (active[i] == 0) or resume instances.  A parked instance is skipped by lpbox_iterate / _l2f and keeps its
+ * state and return code; the reference has no counterpart because its loop simply stops calling a finished solver
+ * (LP/trainer.py:511-512).  active == NULL resumes all. */
+int lpbox_set_active(lpbox_t *h, const int *active);
+/* The same (rows x ws) row-major windows for the WHOLE batch, left on the device: instance idx starts at dev_ptr + idx*stride
+ * doubles and holds lpbox_get_x_iters(h, idx, ws, NULL) rows.  Lets a policy network read the iterates without a host
+ * round trip (valid until the next solver call). */
+int lpbox_get_x_iters_device(lpbox_t *h, int ws, void **dev_ptr, long *stride_doubles);
 int lpbox_get_x_sol(lpbox_t *h, int idx, double *out);        /* LP pxd:17 (LPcpp:1648-1665): out[org_n] in {0,1} */
 int lpbox_get_final_x_sol(lpbox_t *h, int idx, double *out);  /* LP pxd:18 (LPcpp:1668-1685): raw live x, returns its length */
 int lpbox_cal_obj(lpbox_t *h, int idx, double *out);          /* LP pxd:12 cal_obj() (LPcpp:1630-1642)      */

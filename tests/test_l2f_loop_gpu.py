@@ -1,0 +1,43 @@
+"""The early-fixing LOOP around the solver (LP/trainer.py:504-545): the harness in
+lpbox_hip.l2f drives the HIP solver, the same harness drives the oracle, both with the same deterministic policy."""
+import numpy as np
+import pytest
+
+from helpers import bits_equal, lp_instances, oracle_for
+from lpbox_hip import l2f
+from lpbox_hip.lp import LpBatch, PyLPboxADMMsolver
+
+pytestmark = pytest.mark.gpu
+
+
+def _last_iterate(x):                 # policy stand-in: the score of a variable is its latest iterate (exact in float32 on CPU and GPU)
+    return x[:, -1, -1]
+
+
+def test_fix_vector_rule():
+    vec, f1, f0 = l2f.fix_vector_from_scores([0.95, 0.5, 0.05, 0.9, 0.1])
+    assert vec.tolist() == [1.0, -1.0, 0.0, -1.0, -1.0] and (f1, f0) == (1, 1)      # strict > / < (LP/trainer.py:118-125)
+
+
+def test_single_instance_loop_matches_oracle():
+    I = lp_instances("lp_100_500_seed0.npz")[3]
+    g = PyLPboxADMMsolver(0)
+    g.set_problem(I["n"], I["l"], I["colptr"], I["rowidx"], I["b"])
+    g.solve_init()
+    o = oracle_for(g.batch, 0, I)
+    rg = l2f.run_l2f(g, _last_iterate, ws=100)
+    ro = l2f.run_l2f(o, _last_iterate, ws=100)
+    assert rg == ro and rg["fixed"] > 0
+    assert bits_equal(g.get_x_sol(I["n"]), o.get_x_sol(I["n"]))
+
+
+def test_batched_device_loop_matches_per_instance_oracle():
+    insts = lp_instances("lp_100_500_seed0.npz")[:6]
+    b = LpBatch(insts)
+    b.solve_init()
+    res = l2f.run_l2f_batch(b, _last_iterate, ws=100)
+    for i, I in enumerate(insts):
+        o = oracle_for(b, i, I)
+        ro = l2f.run_l2f(o, _last_iterate, ws=100)
+        assert res["objective"][i] == ro["objective"] and res["infeasible"][i] == ro["infeasible"], i
+        assert bits_equal(b.get_x_sol(i).ravel(), o.get_x_sol().ravel()), i
