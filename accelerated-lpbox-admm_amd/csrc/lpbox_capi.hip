@@ -102,6 +102,7 @@ struct lpbox_solver {
     int ws_cap = 0;        // columns of the current xhist staging buffer
     int last_ws = 0;       // window length of the last l2f call
     bool xi_valid = false;
+    bool record = false;   // plain loop keeps x of every iteration (lpbox_set_record; print_fix_info 2/3)
     long xi_out_stride = 0;
     int xi_out_ws = 0;
     std::vector<int> h_isc;   // host mirror, refreshed after every solver call
@@ -568,15 +569,52 @@ int lpbox_init(lpbox_t *h) {
     return 1;                                                              // LPcpp:762
 }
 
+// Upload the per-window control words and clear the x_iters staging buffer (ws columns of NS doubles per instance).
+static int stage_xiters(lpbox_t *h, int ws, const std::vector<int> &h_ctl, const std::vector<double> &h_dctl,
+                        const std::vector<uint8_t> *h_newfix, const std::vector<int> &h_left, const std::vector<int> &h_rows) {
+    const size_t B = h->B, NS = h->NS;
+    if ((double)B * ws * NS * sizeof(double) > 64e9)
+        return fail(LPBOX_E_BADARG, "x history of %d iterations x %zu instances would need %.1f GB", ws, B, (double)B * ws * NS * 8 / 1e9);
+    if (ws > 0 && (h->ws_cap < ws || !h->xhist.p)) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(h->xhist.alloc(B * (size_t)ws * NS));
+        h->ws_cap = ws;
+    }
+    HIPCHK(hipMemcpyAsync(h->ctl.p, h_ctl.data(), h_ctl.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->dctl.p, h_dctl.data(), h_dctl.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (h_newfix) HIPCHK(hipMemcpyAsync(h->newfix.p, h_newfix->data(), h_newfix->size(), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->left_idx.p, h_left.data(), h_left.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->xi_rows.p, h_rows.data(), h_rows.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    if (ws > 0) HIPCHK(hipMemsetAsync(h->xhist.p, 0, B * (size_t)h->ws_cap * NS * sizeof(double), h->stream));   // x_iters starts as zeros
+    return LPBOX_OK;
+}
+
 int lpbox_iterate(lpbox_t *h, int iter_start, int iter_end, int *rets) {
     if (valid_handle(h) && h->seg) return fail(LPBOX_E_STATE, "this entry point belongs to the LP flavour");
     if (!valid_handle(h)) return fail(LPBOX_E_BADHANDLE, "bad handle");
     if (!h->inited) return fail(LPBOX_E_STATE, "solve_init has not been called");
     int rc = use_device(h);
     if (rc) return rc;
-    HIPCHK(hipMemsetAsync(h->ctl.p, 0, (size_t)h->B * 4 * sizeof(int), h->stream));
-    rc = run_window(h, iter_start, iter_end, 0);
+    const bool rec = h->record && iter_end > iter_start;
+    if (rec) {                         // print_fix_info 2/3 (LPcpp:776-779,903-909): keep x of every iteration of this call
+        const size_t B = h->B, NS = h->NS;
+        std::vector<int> h_ctl(B * 4, 0), h_rows(B, 0), h_left(B * NS, 0);
+        std::vector<double> h_dctl(B, 0.0);
+        for (size_t i = 0; i < B; i++) {
+            LpInstance &I = h->inst[i];
+            I.xi_rows = (int)I.left_idx.size();
+            I.xi_left_idx = I.left_idx;
+            h_rows[i] = I.xi_rows;
+            for (int q = 0; q < I.xi_rows; q++) h_left[i * NS + q] = I.cpos[I.left_idx[q]];
+        }
+        rc = stage_xiters(h, iter_end - iter_start, h_ctl, h_dctl, nullptr, h_left, h_rows);
+        if (rc) return rc;
+    } else {
+        HIPCHK(hipMemsetAsync(h->ctl.p, 0, (size_t)h->B * 4 * sizeof(int), h->stream));
+    }
+    rc = run_window(h, iter_start, iter_end, rec ? 2 : 0);
     if (rc) return rc;
+    if (rec) { h->last_ws = iter_end - iter_start; h->xi_valid = true; h->xi_out_ws = 0; }
     for (int i = 0; i < h->B; i++)
         if (rets) rets[i] = h->h_isc[(size_t)i * NI_COUNT + NI_RET];
     return h->h_isc[NI_RET];
@@ -645,18 +683,9 @@ int lpbox_iterate_l2f(lpbox_t *h, int iter_start, int iter_end, const double *ve
         h_rows[i] = I.xi_rows;
         for (int q = 0; q < I.xi_rows; q++) h_left[i * NS + q] = I.cpos[I.left_idx[q]];   // storage position of the q-th live variable
     }
-    if (ws > 0 && (h->ws_cap < ws || !h->xhist.p)) {
-        HIPCHK(hipStreamSynchronize(h->stream));
-        HIPCHK(h->xhist.alloc(B * (size_t)ws * NS));
-        h->ws_cap = ws;
-    }
-    HIPCHK(hipMemcpyAsync(h->ctl.p, h_ctl.data(), h_ctl.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->dctl.p, h_dctl.data(), h_dctl.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    if (any_fix) HIPCHK(hipMemcpyAsync(h->newfix.p, h_newfix.data(), h_newfix.size(), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->left_idx.p, h_left.data(), h_left.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->xi_rows.p, h_rows.data(), h_rows.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    if (ws > 0) HIPCHK(hipMemsetAsync(h->xhist.p, 0, B * (size_t)h->ws_cap * NS * sizeof(double), h->stream));   // x_iters starts as zeros
-    rc = run_window(h, iter_start, iter_end, 1);    // synchronises: the host staging vectors above stay alive until here
+    rc = stage_xiters(h, ws, h_ctl, h_dctl, any_fix ? &h_newfix : nullptr, h_left, h_rows);
+    if (rc) return rc;
+    rc = run_window(h, iter_start, iter_end, 3);    // synchronises: the host staging vectors above stay alive until here
     if (rc) return rc;
     h->last_ws = ws;
     h->xi_valid = true;
@@ -665,6 +694,18 @@ int lpbox_iterate_l2f(lpbox_t *h, int iter_start, int iter_end, const double *ve
         if (rets) rets[i] = h->h_isc[i * NI_COUNT + NI_RET];
     }
     return h->h_isc[NI_RET];
+}
+
+int lpbox_set_record(lpbox_t *h, int on) {
+    if (!valid_handle(h)) return fail(LPBOX_E_BADHANDLE, "bad handle");
+    if (h->seg) return segc_set_record(h->seg, on);
+    h->record = on != 0;
+    return LPBOX_OK;
+}
+
+int lpbox_seg_get_x_history(lpbox_t *h, int first, int count, double *out) {
+    if (!valid_handle(h) || !h->seg) return fail(LPBOX_E_BADHANDLE, "bad handle (segmentation flavour only)");
+    return segc_get_x_history(h->seg, first, count, out);
 }
 
 int lpbox_set_active(lpbox_t *h, const int *active) {
@@ -713,7 +754,8 @@ int lpbox_get_x_iters(lpbox_t *h, int idx, int ws, double *out) {
     int rc = check_idx(h, idx);
     if (rc) return rc;
     if (!h->xi_valid) return fail(LPBOX_E_STATE, "solve_iter_l2f has not been called");
-    if (ws < 0 || ws > LP_XITERS_COLS) return fail(LPBOX_E_BADARG, "ws = %d outside [0,%d]", ws, LP_XITERS_COLS);
+    const int ws_max = std::max(LP_XITERS_COLS, h->ws_cap);      // x_iters has 500 columns (LPcpp:1113); a recorded plain window may be longer
+    if (ws < 0 || ws > ws_max) return fail(LPBOX_E_BADARG, "ws = %d outside [0,%d]", ws, ws_max);
     const int rows = h->inst[idx].xi_rows;
     if (!out || rows == 0 || ws == 0) return rows;
     rc = use_device(h);

@@ -18,6 +18,8 @@ int segc_get_n(SegSolver *s);
 int segc_get_org_n(SegSolver *s);
 int segc_get_iter(SegSolver *s);
 int segc_get_x_iters(SegSolver *s, int ws, double *out);
+int segc_set_record(SegSolver *s, int on);
+int segc_get_x_history(SegSolver *s, int first, int count, double *out);
 int segc_get_x_sol(SegSolver *s, double *out);
 int segc_get_obj(SegSolver *s, double *out);
 int segc_get_shape(SegSolver *s, int *rows, int *cols);

@@ -269,7 +269,8 @@ __global__ void __launch_bounds__(T) lp_init_kernel(LpBatchDev bd, const double 
 //   RCAPS / CCAPS  per-slot register capacities (Caps<...>) of the row-task / column gather lists.
 // ------------------------------------------------------------------------------------------------
 template <int T, int EPT, typename RCAPS, typename CCAPS>
-__global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_start, int iter_end, int l2f) {
+__global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_start, int iter_end, int mode) {
+    const int l2f = mode & 1, rec = mode & 2;     // rec: keep x after every iteration in xhist (x_iters of the l2f loop; print_fix_info 2/3 of the plain loop)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int inst = blockIdx.x, tid = threadIdx.x;
     int *isc = bd.isc + (size_t)inst * NI_COUNT;
@@ -602,7 +603,7 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
 #pragma unroll
             for (int s = 0; s < EPT; s++) x[s] = live[s] ? xt[s] : x[s];
             outer_total++;
-            if (l2f) {                                                // x_iters column cc (:1472-1475)
+            if (rec) {                                                // x_iters column cc (:1472-1475); plain loop: the xiter dump (:903-909)
                 double *xh = bd.xhist + ((size_t)inst * bd.ws_cap + cc) * bd.NS;
 #pragma unroll
                 for (int s = 0; s < EPT; s++) if (valid[s]) xh[s * T + tid] = x[s];

@@ -25,6 +25,7 @@
 #define SEG_PCG_TOL       1e-3                 // :671
 #define SEG_PCG_MAXITERS  1000                 // :672
 #define SEG_XITERS_COLS   10                   // :924
+#define SEG_REC_COLS      2000                 // default capacity (iterations) of a recorded legacy solve
 
 #define SEG_T 256
 #define SEG_NPART 8        // partial-sum slots per phase
@@ -46,6 +47,7 @@ struct SegState {
     int pcg_done;
     int have_prev;       // an iteration's partE is waiting to be finalised
     int halt, stop, ret, l2f, cc;
+    int rec;             // keep x of every iteration in xhist column cc (x_iters of the l2f loop; print_info 1 of the legacy loop)
     int pcg_total, outer_total, last_pcg, legacy_iter_p1;
     int pcg_max;         // largest PCG iteration count since the host last reset it (drives the adaptive launch count)
     int dinv_stale;      // a fix rebuilt the diagonal while no rho update was pending (stale preconditioner = UB in the reference)

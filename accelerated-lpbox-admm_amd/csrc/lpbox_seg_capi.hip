@@ -51,6 +51,8 @@ struct SegSolver {
     Buf<uint8_t> live, fixval, newfix;
     Buf<SegState> st;
     int ws_cap = 0, last_ws = 0;
+    int record = 0;        // legacy loop keeps x of up to `record` iterations (lpbox_set_record; print_info 1, SEGcpp:1209-1213,1270-1277)
+    int rec_cols = 0;      // iterations the last legacy solve recorded
     SegState hst;
 
     SegDev dev() const {
@@ -351,9 +353,16 @@ int segc_legacy(SegSolver *s, int *energy) {                                  //
     if (!s->inited) return lpbox_fail(LPBOX_E_STATE, "solve_init has not been called");
     int rc = use_device(s);
     if (rc) return rc;
-    HIPCHK(seg_launch_set_window(s->dev(), 0, SEG_MAX_ITERS, 0, &s->parity, s->stream));
+    if (s->record > 0 && (!s->xhist.p || s->ws_cap < s->record)) {
+        HIPCHK(hipStreamSynchronize(s->stream));
+        HIPCHK(s->xhist.alloc((size_t)s->record * s->n)); s->ws_cap = s->record; drop_graphs(s);
+        HIPCHK(hipMemsetAsync(s->xhist.p, 0, sizeof(double) * (size_t)s->ws_cap * s->n, s->stream));
+    }
+    HIPCHK(seg_launch_set_window(s->dev(), 0, SEG_MAX_ITERS, s->record > 0 ? 2 : 0, &s->parity, s->stream));
     rc = run_window(s, SEG_MAX_ITERS);
     if (rc) return rc;
+    s->rec_cols = s->record > 0 ? std::min(s->hst.cc, s->ws_cap) : 0;
+    s->xi_valid = false;
     if (energy) *energy = (int)(s->hst.cur_obj + s->c);                        // :1379
     return LPBOX_OK;
 }
@@ -372,7 +381,7 @@ int segc_l2f(SegSolver *s, int iter_start, int iter_end, const double *vec, int 
         for (int q = 0; q < n_live; q++) if (vec[q] == 1 || vec[q] == 0) cnt++;
         if (cnt != num) return lpbox_fail(LPBOX_E_BADARG, "vec fixes %d variables but num = %d", cnt, num);
     }
-    HIPCHK(seg_launch_set_window(s->dev(), iter_start, iter_end, 1, &s->parity, s->stream));
+    HIPCHK(seg_launch_set_window(s->dev(), iter_start, iter_end, 3, &s->parity, s->stream));
     if (num != 0) {
         std::vector<uint8_t> nf(s->n, 0);
         std::vector<int> keep; keep.reserve(n_live - num);
@@ -390,7 +399,8 @@ int segc_l2f(SegSolver *s, int iter_start, int iter_end, const double *vec, int 
         HIPCHK(hipStreamSynchronize(s->stream));
         HIPCHK(s->xhist.alloc((size_t)SEG_XITERS_COLS * s->n)); s->ws_cap = SEG_XITERS_COLS; drop_graphs(s);
     }
-    if (ws > 0) HIPCHK(hipMemsetAsync(s->xhist.p, 0, sizeof(double) * (size_t)s->ws_cap * s->n, s->stream));
+    if (ws > 0) HIPCHK(hipMemsetAsync(s->xhist.p, 0, sizeof(double) * (size_t)ws * s->n, s->stream));   // columns [0, ws) of this window
+    s->rec_cols = 0;
     if (!s->left_idx.empty()) HIPCHK(hipMemcpyAsync(s->d_left.p, s->left_idx.data(), sizeof(int) * s->left_idx.size(), hipMemcpyHostToDevice, s->stream));
     rc = run_window(s, iter_end);
     if (rc) return rc;
@@ -403,6 +413,21 @@ int segc_get_n(SegSolver *s) { return s->inited ? s->hst.n_live : s->n; }
 int segc_get_org_n(SegSolver *s) { return s->n; }
 int segc_get_iter(SegSolver *s) { return s->inited ? s->hst.iter : 0; }
 int segc_get_shape(SegSolver *s, int *rows, int *cols) { if (rows) *rows = s->rows; if (cols) *cols = s->cols; return LPBOX_OK; }
+
+int segc_set_record(SegSolver *s, int on) {
+    s->record = on <= 0 ? 0 : (on == 1 ? SEG_REC_COLS : on);
+    return LPBOX_OK;
+}
+
+int segc_get_x_history(SegSolver *s, int first, int count, double *out) {     // rows of ../xiter/<problem>.csv (SEGcpp:1270-1277)
+    if (!out) return s->rec_cols;
+    if (first < 0 || count < 0 || first + count > s->rec_cols)
+        return lpbox_fail(LPBOX_E_BADARG, "iterations [%d,%d) outside the %d recorded", first, first + count, s->rec_cols);
+    int rc = use_device(s);
+    if (rc) return rc;
+    if (count) HIPCHK(hipMemcpy(out, s->xhist.p + (size_t)first * s->n, sizeof(double) * (size_t)count * s->n, hipMemcpyDeviceToHost));
+    return count;
+}
 
 int segc_get_x_iters(SegSolver *s, int ws, double *out) {                     // get_x_iters_d SEGcpp:839-851
     if (!s->xi_valid) return lpbox_fail(LPBOX_E_STATE, "solve_iter_l2f has not been called");

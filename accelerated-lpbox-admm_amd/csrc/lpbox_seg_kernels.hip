@@ -100,10 +100,11 @@ __global__ void __launch_bounds__(T) seg_k_init(SegDev d, double c1) {      // A
     }
 }
 
-__global__ void seg_k_set_window(SegDev d, int in, int out, int iter_start, int iter_end, int l2f) {
+__global__ void seg_k_set_window(SegDev d, int in, int out, int iter_start, int iter_end, int mode) {
+    const int l2f = mode & 1;
     d.st[out] = d.st[in];
     SegState *s = d.st + out;
-    s->iter = iter_start; s->iter_end = iter_end; s->l2f = l2f; s->cc = 0; s->ret = 0; s->stop = SEG_STOP_NONE;
+    s->iter = iter_start; s->iter_end = iter_end; s->l2f = l2f; s->rec = (mode >> 1) & 1; s->cc = 0; s->ret = 0; s->stop = SEG_STOP_NONE;
     if (s->halt != SEG_HALT_ALLFIXED) s->halt = SEG_HALT_NONE;
 }
 
@@ -385,7 +386,7 @@ __global__ void __launch_bounds__(T) seg_k_post(SegDev d, int in, int out) {
     int parity = 0;
     const SegState *si = d.st + in;
     if (si->halt || si->phase != 2) { forward_state(d, in, out); return; }
-    const int pcg_k = si->pcg_k, l2f = si->l2f, cc = si->cc;
+    const int pcg_k = si->pcg_k, rec = si->rec, cc = si->cc;
     int done = si->pcg_done;
     if (!done) {                           // the exit test of the last update is still pending
         double d2[2];
@@ -396,7 +397,7 @@ __global__ void __launch_bounds__(T) seg_k_post(SegDev d, int in, int out) {
     const double g1 = si->gamma_val * si->rho1, g2 = si->gamma_val * si->rho2;
     const double *x = d.x;
     double e5[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, e2[2] = {0.0, 0.0};
-    double *xh = l2f ? d.xhist + (size_t)cc * d.n : nullptr;
+    double *xh = (rec && cc < d.ws_cap) ? d.xhist + (size_t)cc * d.n : nullptr;
     for (int q = 0; q < d.EPT; q++) {
         const int i = blockIdx.x * (T * d.EPT) + q * T + threadIdx.x;
         double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0, v4 = 0.0, v5 = 0.0, v6 = 0.0;
@@ -435,7 +436,7 @@ __global__ void __launch_bounds__(T) seg_k_post(SegDev d, int in, int out) {
         SegState *s = d.st + out;
         s->pcg_done = 1; s->last_pcg = pcg_k; s->pcg_total += pcg_k; s->outer_total++;
         if (pcg_k > s->pcg_max) s->pcg_max = pcg_k;
-        if (l2f) s->cc = cc + 1;
+        if (rec) s->cc = cc + 1;
         s->have_prev = 1; s->phase = 0;
     }
 }
@@ -463,8 +464,8 @@ hipError_t seg_launch_init(const SegDev &d, double c1, hipStream_t s) {
         *parity ^= 1;                                                                        \
     } while (0)
 
-hipError_t seg_launch_set_window(const SegDev &d, int iter_start, int iter_end, int l2f, int *parity, hipStream_t s) {
-    hipLaunchKernelGGL(seg_k_set_window, dim3(1), dim3(1), 0, s, d, *parity, *parity ^ 1, iter_start, iter_end, l2f);
+hipError_t seg_launch_set_window(const SegDev &d, int iter_start, int iter_end, int mode, int *parity, hipStream_t s) {
+    hipLaunchKernelGGL(seg_k_set_window, dim3(1), dim3(1), 0, s, d, *parity, *parity ^ 1, iter_start, iter_end, mode);
     *parity ^= 1;
     return hipGetLastError();
 }

@@ -38,6 +38,8 @@ SYMBOLS = {
     "lpbox_get_l": (C.c_int, [C.c_void_p, C.c_int]),
     "lpbox_get_iter": (C.c_int, [C.c_void_p, C.c_int]),
     "lpbox_get_x_iters": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "lpbox_set_record": (C.c_int, [C.c_void_p, C.c_int]),
+    "lpbox_seg_get_x_history": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "lpbox_set_active": (C.c_int, [C.c_void_p, C.c_void_p]),
     "lpbox_get_x_iters_device": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_long)]),
     "lpbox_get_x_sol": (C.c_int, [C.c_void_p, C.c_int, _dp]),

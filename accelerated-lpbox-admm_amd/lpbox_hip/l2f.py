@@ -68,3 +68,32 @@ def run_l2f_batch(batch, score_fn_torch, ws=100, max_iter=10000, tokens=20, min_
                 nums[i] = k
     return dict(objective=np.array([-batch.cal_obj(i) for i in range(B)]),
                 infeasible=np.array([batch.check_infeasible_l2f(i) for i in range(B)]), windows=w + 1)
+
+
+def sliding_windows(xiters, tokens=5, width=5):
+    """SEG/trainer.py:721-725: token j of a variable = its iterates j .. j+width-1."""
+    a = xiters.shape[0]
+    out = np.zeros((a, tokens, width))
+    for j in range(tokens):
+        out[:, j, :] = xiters[:, j:j + width]
+    return out
+
+
+def run_l2f_seg(solver, score_fn, ws=10, max_iter=30, min_fix=10):
+    """The segmentation validation loop (SEG/trainer.py:699-745): solver is a SEG PyLPboxADMMsolver after solve_init();
+    score_fn maps a float32 array (n_live, 5, 5) to sigmoid scores.  Returns dict(energy, windows, fixed)."""
+    n = 0
+    vec = np.zeros(solver.get_n(), dtype=np.double)
+    windows = fixed = 0
+    for i in range(int(max_iter / ws)):
+        ret = solver.solve_iter_l2f(ws * i, ws * (i + 1), vec, n)
+        windows += 1
+        fixed += n
+        if ret:
+            break
+        x = sliding_windows(solver.get_x_iters_2d(ws)).astype(np.float32)
+        vec, f1, f0 = fix_vector_from_scores(score_fn(x))
+        n = f1 + f0
+        if n <= min_fix:                                                              # SEG/trainer.py:735-736
+            n = 0
+    return dict(energy=solver.get_obj(), windows=windows, fixed=fixed)

@@ -8,6 +8,7 @@ Reference citations: LPcpp = LinerProgramming/LinearProgramming/cython_solver/LP
 """
 import ctypes as C
 import os
+import time
 
 import numpy as np
 
@@ -84,6 +85,11 @@ class LpBatch:
     # ---- solver ----
     def solve_init(self):
         return check(self._L.lpbox_init(self._h), "lpbox_init")
+
+    def set_record(self, on=True):
+        """Plain loop keeps x of every iteration of a solve_iter call (print_fix_info 2/3, LPcpp:903-909); read them with
+        get_x_iters_2d(j - i)."""
+        check(self._L.lpbox_set_record(self._h, 1 if on else 0), "lpbox_set_record")
 
     def solve_iter(self, i, j):
         rets = np.zeros(self.B, np.int32)
@@ -229,6 +235,10 @@ class PyLPboxADMMsolver:
 
     data_root = None
     verbose = False
+    # Side-effect files of ADMM_lp_iters (LPcpp:776-783, 903-909, 940-946, 986-992, 1081): <root>/xiter/allres.csv gets one line
+    # per plain solve and, for print_info 2/3, <root>/xiter/<k>_<j>_xiters_<i>.csv the iterates.  None: write them iff
+    # <root>/xiter exists (the reference crashes without it); True: create the directory; False: never.
+    write_files = None
 
     def __init__(self, print_info=0, *unused):
         if unused:
@@ -243,6 +253,8 @@ class PyLPboxADMMsolver:
     def read_File(self, i, k, j):
         root = self.data_root or os.environ.get("LPBOX_DATA_ROOT")
         self._b.read_file(0, _as_int(i, "i"), _as_int(k, "k"), _as_int(j, "j"), root)
+        self._file_id = (int(i), int(k), int(j))
+        self._root = root if root is not None else os.path.join("..", "cython_solver", "data")      # LPcpp:2451
         return None
 
     # extension: hand the problem over in memory instead of through the instance files
@@ -255,9 +267,37 @@ class PyLPboxADMMsolver:
 
     # LP pyx:22-23
     def solve_iter(self, i, j):
+        out_dir = self._xiter_dir()
+        dump = out_dir is not None and self.print_info in (2, 3) and _as_int(j, "j") > _as_int(i, "i")
+        self._b.set_record(dump)
+        t0 = time.perf_counter()
         ret = int(self._b.solve_iter(i, j)[0])
+        secs = int((time.perf_counter() - t0) * 1000) / 1000.0          # the reference truncates to whole ms (LPcpp:1079-1080)
         self._echo_stop(plain=True)
+        if out_dir is not None:
+            self._write_plain_files(out_dir, int(i), int(j), secs, dump)
         return ret
+
+    def _xiter_dir(self):
+        if self.write_files is False or getattr(self, "_file_id", None) is None:
+            return None
+        d = os.path.join(self._root, "xiter")
+        if self.write_files:
+            os.makedirs(d, exist_ok=True)
+        return d if os.path.isdir(d) else None
+
+    def _write_plain_files(self, out_dir, i, j, secs, dump):
+        fi, k, jj = self._file_id
+        reason, p1 = self._b.stop(0)
+        if dump:
+            done = (p1 - i) if reason in (1, 2) else (j - i)           # iterations this call ran (break leaves iter at the stop)
+            with open(os.path.join(out_dir, "%d_%d_xiters_%d.csv" % (k, jj, fi)), "w") as f:      # "w+" (LPcpp:778)
+                X = self._b.get_x_iters_2d(j - i, 0)[:, :done].T       # one row per iteration
+                rows = range(done) if self.print_info == 2 else (range(done - 1, done) if reason in (1, 2) else range(0))
+                for r in rows:
+                    f.write("Iter%d," % (i + r + 1) + ",".join("%f" % v for v in X[r]) + "\n")
+        with open(os.path.join(out_dir, "allres.csv"), "a") as f:      # "%d,%f,%d,%f" (LPcpp:1081)
+            f.write("%d,%f,%d,%f\n" % (fi, -self._b.cur_bin_obj(0), p1, secs))
 
     # LP pyx:25-26
     def cal_Obj(self):

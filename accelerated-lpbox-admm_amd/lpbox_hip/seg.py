@@ -7,6 +7,7 @@ resize (cv::resize INTER_LINEAR) and the cost construction (SEGcpp:46-248) run i
 """
 import ctypes as C
 import os
+import time
 
 import numpy as np
 
@@ -29,6 +30,11 @@ class PyLPboxADMMsolver:
     data_root = None      # directory holding <problem>.jpg; default: the reference's CWD-relative "../data" (SEGcpp:690)
     result_root = None    # directory for save_img(); default "../result" (SEGcpp:691)
     verbose = False
+    # Side-effect files of the legacy loop (SEGcpp:690-700, 1209-1216, 1270-1277, 1376): <result_root>/xiter_all.csv gets one
+    # line per solve and, for print_info 1, <xiter_root>/<problem>.csv every iterate.  None: write where the directory exists
+    # (the reference crashes without it); True: create the directories; False: never.
+    write_files = None
+    xiter_root = None     # default "../xiter" (SEGcpp:696)
 
     def __init__(self, print_info=0, numNodes=10000, problem=0):
         self._L = _lib.load()
@@ -88,9 +94,41 @@ class PyLPboxADMMsolver:
 
     # SEG pyx:20-21
     def solve_iter(self):
+        xdir = self._out_dir(self.xiter_root or "../xiter") if self.print_info == 1 else None
+        rdir = self._out_dir(self.result_root or "../result")
+        check(self._L.lpbox_set_record(self._h, 1 if xdir else 0), "lpbox_set_record")
         e = C.c_int()
+        t0 = time.perf_counter()
         check(self._L.lpbox_seg_legacy(self._h, C.byref(e)), "lpbox_seg_legacy")
+        ms = int((time.perf_counter() - t0) * 1000)
+        if xdir:
+            self._write_xiters(os.path.join(xdir, "%d.csv" % self.problem))
+        if rdir:
+            obj, c = self.debug_scalar("cur_obj"), self.debug_scalar("c")
+            with open(os.path.join(rdir, "xiter_all.csv"), "a") as f:          # "%d,%f,%f,%d,%f" (SEGcpp:1376)
+                f.write("%d,%f,%f,%d,%f\n" % (self.problem, obj, obj + c, self.stop()[1], ms * 1.0 / 1000))
         return e.value
+
+    def _out_dir(self, d):
+        if self.write_files is False:
+            return None
+        if self.write_files:
+            os.makedirs(d, exist_ok=True)
+        return d if os.path.isdir(d) else None
+
+    def x_history(self):
+        """(iterations x org_n) iterates of the last recorded legacy solve (lpbox_set_record)."""
+        k = check(self._L.lpbox_seg_get_x_history(self._h, 0, 0, None), "lpbox_seg_get_x_history")
+        out = np.zeros((k, self.get_org_n()))
+        if k:
+            check(self._L.lpbox_seg_get_x_history(self._h, 0, k, out.ctypes.data_as(C.c_void_p)), "lpbox_seg_get_x_history")
+        return out
+
+    def _write_xiters(self, path):
+        X = self.x_history()
+        with open(path, "w") as f:                                              # "Iter%d,%lf,...,%lf" (SEGcpp:1270-1277)
+            for r in range(X.shape[0]):
+                f.write("Iter%d," % (r + 1) + ",".join(map("%f".__mod__, X[r])) + "\n")
 
     # SEG pyx:23-24
     def solve_iter_l2f(self, i, j, vec, num):

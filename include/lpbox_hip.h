@@ -83,6 +83,15 @@ int lpbox_get_iter(lpbox_t *h, int idx);                      /* LP pxd:16 get_i
 /* LP pxd:14 `double* get_x_iters_d(int)` (LPcpp:1616-1627): out[rows*ws] row-major, rows = n_live of the last
  * l2f call; returns rows.  out may be NULL to query rows. */
 int lpbox_get_x_iters(lpbox_t *h, int idx, int ws, double *out);
+/* Plain loop with print_fix_info 2/3 (LPcpp:776-779, 903-909, 940-946, 986-992): the reference streams x_sol of every iteration to
+ * <root>/xiter/<k>_<j>_xiters_<i>.csv.  With record on, lpbox_iterate keeps those iterates on the device (one column per iteration of the
+ * call, exactly like the x_iters window of the l2f loop) and lpbox_get_x_iters / _device hand them out; the CSV itself is written by the
+ * host wrapper.  Off by default. */
+int lpbox_set_record(lpbox_t *h, int on);
+/* Segmentation flavour: with record on (on == 1: up to 2000 iterations, on > 1: that many), lpbox_seg_legacy keeps x_sol of every iteration
+ * (print_info 1 -> ../xiter/<problem>.csv, SEGcpp:1209-1213, 1270-1277).  out == NULL: number of iterations recorded; otherwise copies
+ * iterations [first, first+count) as count rows of org_n doubles. */
+int lpbox_seg_get_x_history(lpbox_t *h, int first, int count, double *out);
 /* Batched use only: park (active[i] == 0) or resume instances.  A parked instance is skipped by lpbox_iterate / _l2f and keeps its
  * state and return code; the reference has no counterpart because its loop simply stops calling a finished solver
  * (LP/trainer.py:511-512).  active == NULL resumes all. */
