@@ -7,6 +7,7 @@
 #include "../../include/lpbox_hip.h"
 #include "lpbox_lp.h"
 #include "lpbox_capi_internal.h"
+#include "lpbox_policy.h"
 
 #include <algorithm>
 #include <cmath>
@@ -706,6 +707,26 @@ int lpbox_set_record(lpbox_t *h, int on) {
 int lpbox_seg_get_x_history(lpbox_t *h, int first, int count, double *out) {
     if (!valid_handle(h) || !h->seg) return fail(LPBOX_E_BADHANDLE, "bad handle (segmentation flavour only)");
     return segc_get_x_history(h->seg, first, count, out);
+}
+
+int lpbox_policy_layout(int tokens, long *weight_halves, long *const_floats) {
+    if (tokens != 20 && tokens != 5) return fail(LPBOX_E_BADARG, "tokens must be 20 (LP) or 5 (segmentation)");
+    if (weight_halves) *weight_halves = 2L * POLICY_FRAGS_PER_LAYER * 512;
+    if (const_floats) *const_floats = POLICY_OFF_LAYER(tokens) + 2L * POLICY_LAYER_CONSTS;
+    return LPBOX_OK;
+}
+
+int lpbox_policy_encode_f16(const double *x_dev, const long long *row_off_dev, long rows, int tokens, int tok_stride,
+                            const void *weights_dev, const float *consts_dev, void *out_dev, void *hip_stream) {
+    if (tokens != 20 && tokens != 5) return fail(LPBOX_E_BADARG, "tokens must be 20 (LP) or 5 (segmentation)");
+    if (rows < 0 || tok_stride < 1) return fail(LPBOX_E_BADARG, "bad rows / token stride");
+    if (rows == 0) return LPBOX_OK;
+    if (!x_dev || !row_off_dev || !weights_dev || !consts_dev || !out_dev) return fail(LPBOX_E_BADARG, "null device pointer");
+    PolicyArgs pa;
+    pa.x = x_dev; pa.row_off = row_off_dev; pa.rows = rows; pa.tok_stride = tok_stride;
+    pa.weights = weights_dev; pa.consts = consts_dev; pa.out = out_dev;
+    HIPCHK(policy_launch_body(pa, tokens, (hipStream_t)hip_stream));
+    return LPBOX_OK;
 }
 
 int lpbox_set_active(lpbox_t *h, const int *active) {

@@ -38,36 +38,52 @@ def run_l2f(solver, score_fn, ws=100, max_iter=10000, col=None, tokens=20, min_f
     return dict(objective=-1.0 * solver.cal_Obj(), infeasible=solver.check_infeasible_l2f(), windows=windows, fixed=fixed)
 
 
-def run_l2f_batch(batch, score_fn_torch, ws=100, max_iter=10000, tokens=20, min_fix=10, C=0.9):
+def run_l2f_batch(batch, score_fn_torch, ws=100, max_iter=10000, tokens=20, min_fix=10, C=0.9, timing=None):
     """The same loop for a whole LpBatch with the policy reading the iterates ON THE DEVICE (no host round trip of x_iters):
-    score_fn_torch(x) maps a float32 CUDA tensor (n_live, tokens, ws/tokens) to sigmoid scores (n_live,)."""
+    score_fn_torch(x) maps a float32 CUDA tensor (rows, tokens, ws/tokens) to sigmoid scores (rows,); it is called once per
+    window on the live variables of ALL unfinished instances stacked.  `timing`, if a dict, receives seconds per phase."""
+    import time
+
     import torch
     B = batch.B
     nmax = max(batch.get_org_n(i) for i in range(B))
     vecs = np.zeros((B, nmax))
     nums = np.zeros(B, np.int32)
     done = np.zeros(B, bool)
+    t = dict(solve=0.0, policy=0.0, host=0.0)
+    windows = 0
     for w in range(int(max_iter / ws)):
+        t0 = time.perf_counter()
         batch.set_active(~done)
         rets = batch.solve_iter_l2f(ws * w, ws * (w + 1), vecs, nums)
+        windows += 1
         done |= rets != 0
+        t1 = time.perf_counter()
+        t["solve"] += t1 - t0
         if done.all():
             break
         flat, stride = batch.x_iters_torch(ws)
+        act = np.flatnonzero(~done)
+        rows = [batch.get_n(int(i)) for i in act]
+        X = torch.cat([flat[i * stride: i * stride + r * ws].view(r, ws) for i, r in zip(act.tolist(), rows)])
+        sig = score_fn_torch(X.view(-1, tokens, ws // tokens).to(torch.float32)).reshape(-1)
+        vec = torch.where(sig > C, 1.0, torch.where(sig < 1 - C, 0.0, -1.0)).to(torch.float64).cpu().numpy()   # deter_fix_2
+        t2 = time.perf_counter()
+        t["policy"] += t2 - t1
         nums[:] = 0
-        for i in range(B):
-            if done[i]:
-                continue
-            rows = batch.get_n(i)
-            x = flat[i * stride: i * stride + rows * ws].view(rows, tokens, ws // tokens).to(torch.float32)
-            sig = score_fn_torch(x).to(torch.float64).reshape(-1)
-            vec = torch.where(sig > C, 1.0, torch.where(sig < 1 - C, 0.0, -1.0))
-            k = int((vec != -1).sum().item())
-            if k > min_fix:
-                vecs[i, :rows] = vec.cpu().numpy()
+        off = 0
+        for i, r in zip(act.tolist(), rows):
+            v = vec[off:off + r]
+            off += r
+            k = int(np.count_nonzero(v != -1))
+            if k > min_fix:                                                           # LP/trainer.py:533-535
+                vecs[i, :r] = v
                 nums[i] = k
+        t["host"] += time.perf_counter() - t2
+    if timing is not None:
+        timing.update(t)
     return dict(objective=np.array([-batch.cal_obj(i) for i in range(B)]),
-                infeasible=np.array([batch.check_infeasible_l2f(i) for i in range(B)]), windows=w + 1)
+                infeasible=np.array([batch.check_infeasible_l2f(i) for i in range(B)]), windows=windows)
 
 
 def sliding_windows(xiters, tokens=5, width=5):

@@ -92,9 +92,17 @@ def main():
     L = _lib.load()
     if L.lpbox_device_count() < 1:
         raise SystemExit("bench.py: no HIP device visible; the HIP path has no CPU fallback")
+    # rehearsal on a one-GPU box only: LPBOX_BENCH_BACKEND=gloo LPBOX_BENCH_DEVICE=0 puts every rank on one card
+    backend = os.environ.get("LPBOX_BENCH_BACKEND", "nccl")
+    if "LPBOX_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["LPBOX_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    red_dev = "cuda" if backend == "nccl" else "cpu"
 
     insts = load_instances(FIXTURE)
     shard = [insts[(i + 0) % len(insts)] for i in range(args.batch)]   # every rank: the same synthetic 256-instance shard
@@ -133,9 +141,9 @@ def main():
 
     t_max, it_total = dt, iters_per_step * args.steps
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        ii = torch.tensor([it_total], dtype=torch.float64, device="cuda")
+        ii = torch.tensor([it_total], dtype=torch.float64, device=red_dev)
         dist.all_reduce(ii, op=dist.ReduceOp.SUM)
         t_max, it_total = float(tt.item()), float(ii.item())
 

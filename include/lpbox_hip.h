@@ -92,6 +92,15 @@ int lpbox_set_record(lpbox_t *h, int on);
  * (print_info 1 -> ../xiter/<problem>.csv, SEGcpp:1209-1213, 1270-1277).  out == NULL: number of iterations recorded; otherwise copies
  * iterations [first, first+count) as count rows of org_n doubles. */
 int lpbox_seg_get_x_history(lpbox_t *h, int first, int count, double *out);
+/* ---- the early-fixing policy's encoder, fused on the device (the step either side of the solver in LP/trainer.py:523-535) ----
+ * GraphAttentionEncoder up to its flatten (LP/mha.py:202-243; SEG/mha.py same with 5 tokens), eval mode, fp16 MFMA with fp32
+ * accumulation.  x_dev: fp64 iterates (typically the buffer lpbox_get_x_iters_device returns); variable r's token t is
+ * x_dev[row_off_dev[r] + t*tok_stride + 0..4] (LP/trainer.py:526-527 -> tok_stride 5, tokens 20; SEG/trainer.py:721-725 ->
+ * tok_stride 1, tokens 5).  weights_dev / consts_dev: packed as csrc/lpbox_policy.h describes (lpbox_hip/policy.py packs a
+ * reference state_dict); lpbox_policy_layout gives their sizes.  out_dev: fp16 [rows][tokens*128].  Asynchronous on hip_stream. */
+int lpbox_policy_layout(int tokens, long *weight_halves, long *const_floats);
+int lpbox_policy_encode_f16(const double *x_dev, const long long *row_off_dev, long rows, int tokens, int tok_stride,
+                            const void *weights_dev, const float *consts_dev, void *out_dev, void *hip_stream);
 /* Batched use only: park (active[i] == 0) or resume instances.  A parked instance is skipped by lpbox_iterate / _l2f and keeps its
  * state and return code; the reference has no counterpart because its loop simply stops calling a finished solver
  * (LP/trainer.py:511-512).  active == NULL resumes all. */

@@ -1,0 +1,84 @@
+"""lpbox_hip/policy.py against golden vectors computed by the reference's own
+GraphAttentionEncoder (tests/golden/make_policy_fixture.py): same weights by formula, same inputs.
+Tolerance: fp32 network, different GEMM association -> 2e-5 absolute on the sigmoid, 2e-4 relative-ish on the logit."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN
+from lpbox_hip import policy as P
+
+sys.path.insert(0, GOLDEN)
+from make_policy_fixture import deterministic_state  # noqa: E402
+
+FIX = np.load(os.path.join(GOLDEN, "policy_reference.npz"))
+
+
+def _policy(tag, tokens, device):
+    shapes = P.reference_state_shapes(tokens)
+    # the fixture lists the reference module's own state_dict names/shapes: ours must be the same set
+    ref = {n: tuple(int(v) for v in s.split(",")) if s else () for n, s in zip(FIX[tag + "_names"], FIX[tag + "_shapes"])}
+    assert ref == {k: tuple(v) for k, v in shapes.items()}
+    return P.EarlyFixPolicy(deterministic_state(shapes), tokens=tokens, device=device, chunk_rows=40)   # 96 rows -> 3 chunks
+
+
+@pytest.mark.parametrize("tag,tokens", [("lp", 20), ("seg", 5)])
+def test_policy_matches_reference_cpu(tag, tokens):
+    pol = _policy(tag, tokens, "cpu")
+    x = torch.from_numpy(FIX[tag + "_x"])
+    lg, sg = pol.logits(x).numpy(), pol(x).numpy()
+    assert np.abs(sg - FIX[tag + "_sigmoid"]).max() < 2e-5
+    assert np.abs(lg - FIX[tag + "_logit"]).max() < 2e-4 * max(1.0, np.abs(FIX[tag + "_logit"]).max())
+
+
+def test_position_code_row0_and_shape():
+    pe = P.position_code(20)
+    assert pe.shape == (20, 5) and pe[0].tolist() == [0.0, 1.0, 0.0, 1.0, 0.0]
+    assert abs(float(pe[3, 0]) - np.sin(3.0)) < 1e-6 and abs(float(pe[3, 3]) - np.cos(3.0 / 10000 ** 0.4)) < 1e-6
+
+
+def test_rejects_foreign_state_dict():
+    sd = P.random_state(20)
+    sd.pop("classify.fc4.bias")
+    with pytest.raises(KeyError):
+        P.EarlyFixPolicy(sd, tokens=20, device="cpu")
+    with pytest.raises(ValueError):
+        P.EarlyFixPolicy(P.random_state(5), tokens=20, device="cpu")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,tokens", [("lp", 20), ("seg", 5)])
+def test_policy_matches_reference_gpu(tag, tokens):
+    pol = _policy(tag, tokens, "cuda")
+    x = torch.from_numpy(FIX[tag + "_x"]).cuda()
+    # the device GEMMs (hipBLASLt) accumulate in another order than the CPU run that produced the vectors: 1e-4 absolute
+    assert np.abs(pol(x).cpu().numpy() - FIX[tag + "_sigmoid"]).max() < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,tokens", [("lp", 20), ("seg", 5)])
+def test_fused_encoder_matches_reference_gpu(tag, tokens):
+    """The fused HIP encoder (fp16 MFMA operands, fp32 accumulation) + half head.
+    (a) against the reference module's fp32 golden vectors.  The fixture's formula weights are a stress case (amplitude
+        1.7/sqrt(fan), logits pile up at one value): fp16 operands cost up to 4e-2 on the logit there - torch's own fp16
+        evaluation of the same weights is off by the same amount - so the bound is 2e-2 on the sigmoid;
+    (b) against the fp32 evaluation with weights drawn like the reference initialises them (mha.py:52-56), on a ragged row
+        count (tail workgroup): 2e-4 on the sigmoid."""
+    sd = deterministic_state(P.reference_state_shapes(tokens))
+    fused = P.FusedEarlyFixPolicy(sd, tokens=tokens, device="cuda")
+    x = torch.from_numpy(FIX[tag + "_x"]).cuda()
+    assert np.abs(fused(x).cpu().numpy() - FIX[tag + "_sigmoid"]).max() < 2e-2
+    h16 = P.EarlyFixPolicy(sd, tokens=tokens, device="cuda", dtype=torch.float16)
+    assert (fused.logits(x) - h16.logits(x)).abs().max().item() < 3e-2          # same arithmetic class as torch's fp16 path
+    sd = P.random_state(tokens, seed=1)
+    fused, ref = P.FusedEarlyFixPolicy(sd, tokens=tokens, device="cuda"), P.EarlyFixPolicy(sd, tokens=tokens, device="cuda")
+    xr = torch.rand(1003, tokens, 5, generator=torch.Generator().manual_seed(3)).cuda()
+    assert (fused(xr) - ref(xr)).abs().max().item() < 2e-4
+    # x_iters-style input: fp64 buffer + row offsets, rows in arbitrary order
+    flat = xr.to(torch.float64).reshape(-1)
+    perm = torch.randperm(1003, generator=torch.Generator().manual_seed(4)).cuda()
+    got = fused.scores_from_xiters(flat, perm * (tokens * 5))
+    assert (got - ref(xr)[perm]).abs().max().item() < 2e-4
