@@ -13,7 +13,9 @@
 //     sit in LDS, rows padded by 16 B so that the 16-byte fragment reads of 16 consecutive rows hit distinct banks;
 //   * weights stream from L2 in the exact per-lane fragment order of v_mfma_f32_16x16x32_f16 (packed once on the host), one
 //     coalesced 1 KiB read per fragment, each reused over the wave's 5 row tiles.
-// GEMMs: v_mfma_f32_16x16x32_f16, fp32 accumulate.  Attention: per (variable, head) S^T = K Q^T is ONE 32x32x16 MFMA (head
+// GEMMs: v_mfma_f32_16x16x32_f16, fp32 accumulate, computed transposed (weights = A operand, activations = B operand) so that a
+// lane's four accumulator registers are four consecutive features of one token: every epilogue store is 8 bytes wide.  The
+// next GEMM's weight fragments are requested before the current GEMM starts (two register sets), hiding the L2 latency.  Attention: per (variable, head) S^T = K Q^T is ONE 32x32x16 MFMA (head
 // dimension 16 = its K); with the keys in the accumulator registers the softmax is in-lane (plus one exchange between the two
 // lane halves), and the normalised probabilities feed P V directly as the A operand of the next MFMA (accumulator-as-operand,
 // no LDS round trip).  Inputs are read straight from the solver's x_iters buffer (fp64), the output is the flattened fp16
@@ -22,6 +24,18 @@
 #include <stdint.h>
 
 #include "lpbox_policy.h"
+
+// timing experiments only (tools/): -DPOL_NO_ATTN / -DPOL_NO_FF cut a phase out; results are then wrong by construction
+#ifdef POL_NO_ATTN
+#define POL_ATTN_PAIRS(n) 0
+#else
+#define POL_ATTN_PAIRS(n) (n)
+#endif
+#ifdef POL_NO_FF
+#define POL_FF_CHUNKS 0
+#else
+#define POL_FF_CHUNKS 4
+#endif
 
 namespace {
 
@@ -36,14 +50,15 @@ constexpr int PM = POLICY_TOKENS_PER_WG;   // 160
 constexpr int E = 128;
 constexpr int LDA = 136;               // halves per row of a 128-wide LDS image
 constexpr int LDQ = 72;                // halves per row of a 64-wide LDS image (Q, K, V of four heads)
-constexpr int QROWS = 176;             // 160 + 16 zeroed pad rows: the 32-row MFMA operands of the last variable stay in bounds
+constexpr int QROWS = 176;             // 160 + 16 pad rows: the 32-row MFMA operands of the last variable stay in bounds
+constexpr int LDV = 184;               // halves per row of the transposed V image [feature][token]: 160 tokens + 24 zeroed pad columns
 constexpr int MT = 5;                  // 16-row tiles per wave (2 x 4 wave grid over 10 x N/16 tiles)
 
 struct Lds {
     f16 h[PM * LDA];          // fp16 image of the residual stream (A operand of the QKV and FF-up GEMMs)
     f16 ao[PM * LDA];         // attention output (A operand of the output projection); start of kernel: staging of x
     union {
-        struct { f16 q[QROWS * LDQ], k[QROWS * LDQ], v[QROWS * LDQ]; } a;
+        struct { f16 q[QROWS * LDQ], k[QROWS * LDQ], vt[64 * LDV]; } a;   // V transposed: the P V product reads 4 keys at a time
         f16 ff[PM * LDA];     // one 128-wide chunk of relu(FF-up)
     } u;
 };
@@ -52,28 +67,37 @@ static_assert(sizeof(Lds) <= 160 * 1024, "LDS budget");
 __device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
-// acc[mt][nt] += A[rows of this wave's 5 row tiles][0, 32 KS) * W[:, this wave's NT column tiles]
-// A: LDS fp16 image with row stride lda (halves).  wp: packed fragments, fragment (n-tile, k-step) at (ntile*KS + ks)*64 + lane.
-template <int NT, int KS>
-__device__ __forceinline__ void gemm_tiles(const f16 *A, int lda, int row0, const f16x8 *wp, int ntile0, f32x4 (&acc)[MT][NT], int lane) {
-    const f16 *arow = A + (size_t)(row0 + (lane & 15)) * lda + 8 * (lane >> 4);
-    f16x8 b[NT], bn[NT];
+// Weight fragments of one GEMM for this wave: KS k-steps x NT feature tiles, 16 bytes per lane each.
+template <int NT>
+struct WFrag { f16x8 v[4][NT]; };
+
+// fragment (feature tile, k-step) at (tile*4 + ks)*64 + lane.  Issued well before use: the loads fly while the previous GEMM runs.
+template <int NT>
+__device__ __forceinline__ void load_w(WFrag<NT> &w, const f16x8 *wp, int tile0, int tstride, int lane) {
 #pragma unroll
-    for (int nt = 0; nt < NT; nt++) b[nt] = wp[((size_t)(ntile0 + nt) * KS) * 64 + lane];
+    for (int nt = 0; nt < NT; nt++)
 #pragma unroll
-    for (int ks = 0; ks < KS; ks++) {
-        if (ks + 1 < KS) {
+        for (int ks = 0; ks < 4; ks++) w.v[ks][nt] = wp[((size_t)(tile0 + nt * tstride) * 4 + ks) * 64 + lane];
+}
+
+// acc[mt][nt] += (W^T)[this wave's NT feature tiles][0,128) * (ACT^T)[0,128)[this wave's 5 token tiles]
+// The weights are the MFMA's A operand and the activations its B operand, so a lane ends up with 4 CONSECUTIVE FEATURES of one
+// token: element r of acc[mt][nt] is token row0 + 16 mt + (lane & 15), feature 16 (tile0 + nt) + 4 (lane >> 4) + r, and an
+// epilogue stores it as one 8-byte LDS write.  ACT: LDS fp16 image with row stride lda (halves).
+// LAST_PLAIN: the last feature tile is computed the other way round (activations = A operand): its lanes then hold 4 consecutive
+// TOKENS of one feature, which is what the transposed V image wants.
+template <int NT, bool LAST_PLAIN = false>
+__device__ __forceinline__ void gemm_tiles(const f16 *act, int lda, int row0, const WFrag<NT> &w, f32x4 (&acc)[MT][NT], int lane) {
+    const f16 *arow = act + (size_t)(row0 + (lane & 15)) * lda + 8 * (lane >> 4);
 #pragma unroll
-            for (int nt = 0; nt < NT; nt++) bn[nt] = wp[((size_t)(ntile0 + nt) * KS + ks + 1) * 64 + lane];
-        }
+    for (int ks = 0; ks < 4; ks++) {
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {
             const f16x8 a = *(const f16x8 *)(arow + (size_t)mt * 16 * lda + ks * 32);
 #pragma unroll
-            for (int nt = 0; nt < NT; nt++) acc[mt][nt] = mfma16(a, b[nt], acc[mt][nt]);
+            for (int nt = 0; nt < NT; nt++)
+                acc[mt][nt] = (LAST_PLAIN && nt == NT - 1) ? mfma16(a, w.v[ks][nt], acc[mt][nt]) : mfma16(w.v[ks][nt], a, acc[mt][nt]);
         }
-#pragma unroll
-        for (int nt = 0; nt < NT; nt++) b[nt] = bn[nt];
     }
 }
 
@@ -85,7 +109,17 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[MT][NT]) {
         for (int nt = 0; nt < NT; nt++) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
-// element (mt, nt, r) of a wave's accumulator tiles: row = row0 + 16 mt + 4 (lane>>4) + r, column = 16 (ntile0 + nt) + (lane & 15)
+// value of the same lane in the other half of the wave (lanes l and l ^ 32), combined by the caller
+__device__ __forceinline__ float swap_halves(float v) {
+    const int x = __float_as_int(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);   // r[0]: lower half's values in both halves, r[1]: upper half's
+    return __int_as_float((threadIdx.x & 32) ? r[0] : r[1]);
+}
+
+__device__ __forceinline__ void store4(f16 *dst, float a, float b, float c, float d) {
+    f16x4 h = {(f16)a, (f16)b, (f16)c, (f16)d};
+    *(f16x4 *)dst = h;
+}
 
 template <int TOK>
 __global__ void __launch_bounds__(PT) policy_body_kernel(PolicyArgs pa) {
@@ -93,10 +127,16 @@ __global__ void __launch_bounds__(PT) policy_body_kernel(PolicyArgs pa) {
     Lds &S = *reinterpret_cast<Lds *>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
-    const int row0 = wm * 80;                       // first token row of this wave's tiles
+    const int row0 = wm * 80;                       // first token of this wave's 5 token tiles
+    const int l15 = lane & 15, g4 = (lane >> 4) * 4;
     constexpr int VARS = PM / TOK;                  // variables per workgroup
     const long var0 = (long)blockIdx.x * VARS;
     const int nvar = (int)min((long)VARS, pa.rows - var0);
+    const f16x8 *wbase = reinterpret_cast<const f16x8 *>(pa.weights);
+
+    WFrag<3> w3a, w3b;
+    WFrag<2> w2a, w2b;
+    load_w<3>(w3a, wbase, wn, 4, lane);             // layer 0: feature tile wn of each of Q, K, V (heads 0-3)
 
     // ---- stage x (fp64 in the solver's buffer) as float [160][5] in the `ao` region; zero the pad rows of Q/K/V ----
     float *xs = reinterpret_cast<float *>(S.ao);
@@ -107,9 +147,11 @@ __global__ void __launch_bounds__(PT) policy_body_kernel(PolicyArgs pa) {
         if (v < nvar) val = (float)pa.x[pa.row_off[var0 + v] + (long)t * pa.tok_stride + c];
         xs[e] = val;
     }
-    for (int e = tid; e < (QROWS - PM) * LDQ; e += PT) {
-        S.u.a.q[PM * LDQ + e] = (f16)0.f; S.u.a.k[PM * LDQ + e] = (f16)0.f; S.u.a.v[PM * LDQ + e] = (f16)0.f;
-    }
+    // pad columns of V^T (keys beyond the last variable's tokens) meet probabilities that are exactly 0: they must be finite.
+    // Nothing else writes them (the FF chunk buffer aliases Q and part of K only).  Pad rows of Q / K may hold anything:
+    // padded queries are never stored, padded keys are masked.
+    static_assert(PM * LDA * 2 <= 2 * QROWS * LDQ * 2, "the FF chunk buffer must not reach the V image");
+    for (int e = tid; e < 64 * (LDV - PM); e += PT) S.u.a.vt[(e / (LDV - PM)) * LDV + PM + e % (LDV - PM)] = (f16)0.f;
     __syncthreads();
 
     // ---- embedding: H = x W_in + (position code W_pos + bias), straight into the accumulator layout ----
@@ -118,20 +160,18 @@ __global__ void __launch_bounds__(PT) policy_body_kernel(PolicyArgs pa) {
         const float *win = pa.consts + POLICY_OFF_WIN, *bin = pa.consts + POLICY_OFF_BIN;
 #pragma unroll
         for (int nt = 0; nt < 2; nt++) {
-            const int col = (wn * 2 + nt) * 16 + (lane & 15);
-            float w[5];
+            const int f0 = (wn * 2 + nt) * 16 + g4;
+            f32x4 w[5];
 #pragma unroll
-            for (int c = 0; c < 5; c++) w[c] = win[c * E + col];
+            for (int c = 0; c < 5; c++) w[c] = *(const f32x4 *)(win + c * E + f0);
 #pragma unroll
-            for (int mt = 0; mt < MT; mt++)
+            for (int mt = 0; mt < MT; mt++) {
+                const int tok = row0 + mt * 16 + l15;
+                f32x4 a = *(const f32x4 *)(bin + (tok % TOK) * E + f0);
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int tok = row0 + mt * 16 + 4 * (lane >> 4) + r;
-                    float a = bin[(tok % TOK) * E + col];
-#pragma unroll
-                    for (int c = 0; c < 5; c++) a += xs[tok * 5 + c] * w[c];
-                    H[mt][nt][r] = a;
-                }
+                for (int c = 0; c < 5; c++) a += xs[tok * 5 + c] * w[c];
+                H[mt][nt] = a;
+            }
         }
     }
     __syncthreads();                                  // xs (aliasing ao) fully read
@@ -139,67 +179,83 @@ __global__ void __launch_bounds__(PT) policy_body_kernel(PolicyArgs pa) {
     for (int mt = 0; mt < MT; mt++)
 #pragma unroll
         for (int nt = 0; nt < 2; nt++)
-#pragma unroll
-            for (int r = 0; r < 4; r++)
-                S.h[(row0 + mt * 16 + 4 * (lane >> 4) + r) * LDA + (wn * 2 + nt) * 16 + (lane & 15)] = (f16)H[mt][nt][r];
+            store4(S.h + (row0 + mt * 16 + l15) * LDA + (wn * 2 + nt) * 16 + g4, H[mt][nt][0], H[mt][nt][1], H[mt][nt][2], H[mt][nt][3]);
     __syncthreads();
 
-    const f16x8 *wbase = reinterpret_cast<const f16x8 *>(pa.weights);
-#pragma unroll 1
+#pragma unroll
     for (int layer = 0; layer < 2; layer++) {
         const f16x8 *wl = wbase + (size_t)layer * POLICY_FRAGS_PER_LAYER * 64;
         const float *cl = pa.consts + POLICY_OFF_LAYER(TOK) + layer * POLICY_LAYER_CONSTS;
 
         // ================= self-attention, four heads at a time =================
-#pragma unroll 1
+#pragma unroll
         for (int half = 0; half < 2; half++) {
-            {   // Q | K | V of heads 4 half .. 4 half + 3:  (160 x 128) x (128 x 192)
+            {   // Q | K | V of heads 4 half .. 4 half + 3:  (160 x 128) x (128 x 192); meanwhile fetch the next GEMM's weights
                 f32x4 acc[MT][3];
                 zero_acc<3>(acc);
-                gemm_tiles<3, 4>(S.h, LDA, row0, wl + (size_t)half * 48 * 64, wn * 3, acc, lane);
+                if (half == 0) { load_w<3>(w3b, wl + (size_t)48 * 64, wn, 4, lane); gemm_tiles<3, true>(S.h, LDA, row0, w3a, acc, lane); }
+                else           { load_w<2>(w2a, wl + (size_t)96 * 64, wn * 2, 1, lane); gemm_tiles<3, true>(S.h, LDA, row0, w3b, acc, lane); }
 #pragma unroll
-                for (int nt = 0; nt < 3; nt++) {
-                    const int gt = wn * 3 + nt;                      // 0..11: 4 tiles each of Q, K, V
-                    f16 *dst = gt < 4 ? S.u.a.q : (gt < 8 ? S.u.a.k : S.u.a.v);
-                    const int col = (gt & 3) * 16 + (lane & 15);
-#pragma unroll
-                    for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-                        for (int r = 0; r < 4; r++)
-                            dst[(row0 + mt * 16 + 4 * (lane >> 4) + r) * LDQ + col] = (f16)acc[mt][nt][r];
+                for (int mt = 0; mt < MT; mt++) {
+                    const int tok = row0 + mt * 16 + l15;
+                    store4(S.u.a.q + tok * LDQ + wn * 16 + g4, acc[mt][0][0], acc[mt][0][1], acc[mt][0][2], acc[mt][0][3]);
+                    store4(S.u.a.k + tok * LDQ + wn * 16 + g4, acc[mt][1][0], acc[mt][1][1], acc[mt][1][2], acc[mt][1][3]);
+                    // V tile: lane = feature wn*16 + l15, registers = tokens row0 + 16 mt + g4 .. + 3
+                    store4(S.u.a.vt + (wn * 16 + l15) * LDV + row0 + mt * 16 + g4, acc[mt][2][0], acc[mt][2][1], acc[mt][2][2], acc[mt][2][3]);
                 }
             }
             __syncthreads();
-            // ---- per (variable, head): S^T = K Q^T (keys in registers, queries on lanes), softmax over registers, O = P V ----
+            // ---- per (variable, head): S^T = K Q^T (keys in registers, queries on lanes), softmax over registers, O^T = V^T P^T ----
             {
                 const int r31 = lane & 31, hf = lane >> 5;
 #pragma unroll 1
-                for (int pair = wave; pair < VARS * 4; pair += PT / 64) {
+                for (int pair = wave; pair < POL_ATTN_PAIRS(VARS * 4); pair += PT / 64) {
                     const int v = pair >> 2, hh = pair & 3;
                     const int tok0 = v * TOK;
                     const int off = (tok0 + r31) * LDQ + hh * 16 + 8 * hf;
                     const f16x8 ka = *(const f16x8 *)(S.u.a.k + off);        // A: row = key r31, k = 8 hf + e
-                    const f16x8 qb = *(const f16x8 *)(S.u.a.q + off);        // B: col = query r31
+                    const f16x8 qb = *(const f16x8 *)(S.u.a.q + off);        // B: col = query r31 (already scaled by 1/sqrt(16), mha.py:42)
+                    // V^T fragments for the second product, requested now: element e of k-step s is key 16 s + 8 (e>>2) + 4 hf + (e&3)
+                    f16x8 vfrag[2];
+                    const f16 *vrow = S.u.a.vt + (hh * 16 + (r31 & 15)) * LDV + tok0 + 4 * hf;
+#pragma unroll
+                    for (int s = 0; s < 2; s++) {
+                        if (16 * s < TOK) {
+                            if (TOK % 4 == 0) {
+                                const f16x4 lo = *(const f16x4 *)(vrow + 16 * s), hi = *(const f16x4 *)(vrow + 16 * s + 8);
+                                vfrag[s] = f16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 8; e++) vfrag[s][e] = vrow[16 * s + 8 * (e >> 2) + (e & 3)];
+                            }
+                        }
+                    }
                     f32x16 st;
 #pragma unroll
                     for (int i = 0; i < 16; i++) st[i] = 0.f;
                     st = mfma32(ka, qb, st);                                   // st[reg]: key (reg&3) + 8 (reg>>2) + 4 hf, query r31
+                    // register i holds key kmin (lower lane half) or kmin + 4 (upper half): valid always / for the lower half only / never
                     float mx = -3.0e38f;
 #pragma unroll
                     for (int i = 0; i < 16; i++) {
-                        const int key = (i & 3) + 8 * (i >> 2) + 4 * hf;
-                        st[i] = key < TOK ? st[i] * 0.25f : -3.0e38f;          // norm factor 1/sqrt(16) (mha.py:42)
-                        mx = fmaxf(mx, st[i]);
+                        const int kmin = (i & 3) + 8 * (i >> 2);
+                        if (kmin >= TOK) continue;
+                        if (kmin + 4 < TOK) mx = fmaxf(mx, st[i]);
+                        else mx = fmaxf(mx, hf == 0 ? st[i] : -3.0e38f);
                     }
-                    mx = fmaxf(mx, __shfl_xor(mx, 32));
+                    mx = fmaxf(mx, swap_halves(mx));
+                    const float mxl = mx * 1.44269504088896f;
                     float sum = 0.f;
 #pragma unroll
                     for (int i = 0; i < 16; i++) {
-                        const int key = (i & 3) + 8 * (i >> 2) + 4 * hf;
-                        st[i] = key < TOK ? __expf(st[i] - mx) : 0.f;
-                        sum += st[i];
+                        const int kmin = (i & 3) + 8 * (i >> 2);
+                        if (kmin >= TOK) { st[i] = 0.f; continue; }
+                        float p = exp2f(fmaf(st[i], 1.44269504088896f, -mxl));
+                        if (kmin + 4 >= TOK) p = hf == 0 ? p : 0.f;
+                        st[i] = p;
+                        sum += p;
                     }
-                    sum += __shfl_xor(sum, 32);
+                    sum += swap_halves(sum);
                     const float inv = 1.f / sum;
                     f32x16 o;
 #pragma unroll
@@ -207,22 +263,16 @@ __global__ void __launch_bounds__(PT) policy_body_kernel(PolicyArgs pa) {
 #pragma unroll
                     for (int s = 0; s < 2; s++) {
                         if (16 * s < TOK) {
-                            f16x8 pfrag, vfrag;
+                            f16x8 pfrag;
 #pragma unroll
-                            for (int e = 0; e < 8; e++) {
-                                pfrag[e] = (f16)(st[8 * s + e] * inv);         // P^T rows 16 s + 8 (e>>2) + 4 hf + (e&3)
-                                const int key = 16 * s + 8 * (e >> 2) + 4 * hf + (e & 3);
-                                vfrag[e] = S.u.a.v[(tok0 + key) * LDQ + hh * 16 + (r31 & 15)];
-                            }
-                            o = mfma32(pfrag, vfrag, o);                       // o[reg]: query (reg&3) + 8 (reg>>2) + 4 hf, dim r31
+                            for (int e = 0; e < 8; e++) pfrag[e] = (f16)(st[8 * s + e] * inv);   // P^T rows 16 s + 8 (e>>2) + 4 hf + (e&3)
+                            o = mfma32(vfrag[s], pfrag, o);                    // o[reg]: dim (reg&3) + 8 (reg>>2) + 4 hf, query r31
                         }
                     }
-                    if (r31 < 16) {
-#pragma unroll
-                        for (int i = 0; i < 16; i++) {
-                            const int qi = (i & 3) + 8 * (i >> 2) + 4 * hf;
-                            if (qi < TOK) S.ao[(tok0 + qi) * LDA + (half * 4 + hh) * 16 + r31] = (f16)o[i];
-                        }
+                    if (r31 < TOK) {
+                        f16 *dst = S.ao + (tok0 + r31) * LDA + (half * 4 + hh) * 16 + 4 * hf;
+                        store4(dst, o[0], o[1], o[2], o[3]);
+                        store4(dst + 8, o[4], o[5], o[6], o[7]);
                     }
                 }
             }
@@ -233,19 +283,18 @@ __global__ void __launch_bounds__(PT) policy_body_kernel(PolicyArgs pa) {
         {
             f32x4 acc[MT][2];
             zero_acc<2>(acc);
-            gemm_tiles<2, 4>(S.ao, LDA, row0, wl + (size_t)96 * 64, wn * 2, acc, lane);
+            load_w<2>(w2b, wl + (size_t)128 * 64, wn * 2, 1, lane);              // FF-up chunk 0
+            gemm_tiles<2>(S.ao, LDA, row0, w2a, acc, lane);
 #pragma unroll
             for (int nt = 0; nt < 2; nt++) {
-                const int col = (wn * 2 + nt) * 16 + (lane & 15);
-                const float s1 = cl[POLICY_LC_S1 + col], t1 = cl[POLICY_LC_T1 + col];
+                const int f0 = (wn * 2 + nt) * 16 + g4;
+                const f32x4 s1 = *(const f32x4 *)(cl + POLICY_LC_S1 + f0), t1 = *(const f32x4 *)(cl + POLICY_LC_T1 + f0);
 #pragma unroll
-                for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const float hv = (H[mt][nt][r] + acc[mt][nt][r]) * s1 + t1;
-                        H[mt][nt][r] = hv;
-                        S.h[(row0 + mt * 16 + 4 * (lane >> 4) + r) * LDA + col] = (f16)hv;
-                    }
+                for (int mt = 0; mt < MT; mt++) {
+                    const f32x4 hv = (H[mt][nt] + acc[mt][nt]) * s1 + t1;
+                    H[mt][nt] = hv;
+                    store4(S.h + (row0 + mt * 16 + l15) * LDA + f0, hv[0], hv[1], hv[2], hv[3]);
+                }
             }
         }
         __syncthreads();
@@ -254,49 +303,44 @@ __global__ void __launch_bounds__(PT) policy_body_kernel(PolicyArgs pa) {
         {
             f32x4 acc2[MT][2];
             zero_acc<2>(acc2);
-#pragma unroll 1
-            for (int c = 0; c < 4; c++) {
+#pragma unroll
+            for (int c = 0; c < POL_FF_CHUNKS; c++) {
                 {
                     f32x4 acc[MT][2];
                     zero_acc<2>(acc);
-                    gemm_tiles<2, 4>(S.h, LDA, row0, wl + (size_t)(128 + c * 32) * 64, wn * 2, acc, lane);
+                    load_w<2>(w2a, wl + (size_t)(256 + c * 32) * 64, wn * 2, 1, lane);      // FF-down chunk c
+                    gemm_tiles<2>(S.h, LDA, row0, w2b, acc, lane);
 #pragma unroll
                     for (int nt = 0; nt < 2; nt++) {
-                        const int col = (wn * 2 + nt) * 16 + (lane & 15);
-                        const float b1 = cl[POLICY_LC_B1 + c * E + col];
+                        const int f0 = (wn * 2 + nt) * 16 + g4;
+                        const f32x4 b1 = *(const f32x4 *)(cl + POLICY_LC_B1 + c * E + f0);
 #pragma unroll
-                        for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-                            for (int r = 0; r < 4; r++)
-                                S.u.ff[(row0 + mt * 16 + 4 * (lane >> 4) + r) * LDA + col] = (f16)fmaxf(acc[mt][nt][r] + b1, 0.f);
+                        for (int mt = 0; mt < MT; mt++) {
+                            const f32x4 hv = acc[mt][nt] + b1;
+                            store4(S.u.ff + (row0 + mt * 16 + l15) * LDA + f0, fmaxf(hv[0], 0.f), fmaxf(hv[1], 0.f), fmaxf(hv[2], 0.f), fmaxf(hv[3], 0.f));
+                        }
                     }
                 }
                 __syncthreads();
-                gemm_tiles<2, 4>(S.u.ff, LDA, row0, wl + (size_t)(256 + c * 32) * 64, wn * 2, acc2, lane);
+                if (c < 3) load_w<2>(w2b, wl + (size_t)(128 + (c + 1) * 32) * 64, wn * 2, 1, lane);                 // next FF-up chunk
+                else if (layer == 0) load_w<3>(w3a, wbase + (size_t)POLICY_FRAGS_PER_LAYER * 64, wn, 4, lane);  // next layer's Q|K|V
+                gemm_tiles<2>(S.u.ff, LDA, row0, w2a, acc2, lane);
                 __syncthreads();
             }
 #pragma unroll
             for (int nt = 0; nt < 2; nt++) {
-                const int col = (wn * 2 + nt) * 16 + (lane & 15);
-                const float b2 = cl[POLICY_LC_B2 + col], s2 = cl[POLICY_LC_S2 + col], t2 = cl[POLICY_LC_T2 + col];
+                const int f0 = (wn * 2 + nt) * 16 + g4;
+                const f32x4 b2 = *(const f32x4 *)(cl + POLICY_LC_B2 + f0), s2 = *(const f32x4 *)(cl + POLICY_LC_S2 + f0),
+                            t2 = *(const f32x4 *)(cl + POLICY_LC_T2 + f0);
 #pragma unroll
-                for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const float hv = (H[mt][nt][r] + acc2[mt][nt][r] + b2) * s2 + t2;
-                        H[mt][nt][r] = hv;
-                        S.h[(row0 + mt * 16 + 4 * (lane >> 4) + r) * LDA + col] = (f16)hv;
-                    }
+                for (int mt = 0; mt < MT; mt++) {
+                    const f32x4 hv = (H[mt][nt] + acc2[mt][nt] + b2) * s2 + t2;
+                    H[mt][nt] = hv;
+                    store4(S.h + (row0 + mt * 16 + l15) * LDA + f0, hv[0], hv[1], hv[2], hv[3]);
+                }
             }
         }
         __syncthreads();
-        if (layer == 0) {      // the FF chunk buffer aliased the Q/K/V images: restore their zero pad rows for the next layer
-            for (int e = tid; e < (QROWS - PM) * LDQ; e += PT) {
-                S.u.a.q[PM * LDQ + e] = (f16)0.f; S.u.a.k[PM * LDQ + e] = (f16)0.f; S.u.a.v[PM * LDQ + e] = (f16)0.f;
-            }
-            // no barrier needed here: the next writers of these images (QKV epilogue) touch rows < 160 only, and the next
-            // readers (attention) sit behind that epilogue's barrier
-        }
     }
 
     // ---- flattened activations (variables x TOK*128, fp16), coalesced 16-byte stores ----

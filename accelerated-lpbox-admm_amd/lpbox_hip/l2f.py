@@ -65,8 +65,15 @@ def run_l2f_batch(batch, score_fn_torch, ws=100, max_iter=10000, tokens=20, min_
         flat, stride = batch.x_iters_torch(ws)
         act = np.flatnonzero(~done)
         rows = [batch.get_n(int(i)) for i in act]
-        X = torch.cat([flat[i * stride: i * stride + r * ws].view(r, ws) for i, r in zip(act.tolist(), rows)])
-        sig = score_fn_torch(X.view(-1, tokens, ws // tokens).to(torch.float32)).reshape(-1)
+        if hasattr(score_fn_torch, "scores_from_xiters"):
+            # fused policy (lpbox_hip.policy.FusedEarlyFixPolicy): reads the fp64 iterates in place, one offset per live variable
+            r = np.asarray(rows, np.int64)
+            first = np.repeat(np.cumsum(r) - r, r)
+            off = np.repeat(act.astype(np.int64) * stride, r) + (np.arange(int(r.sum()), dtype=np.int64) - first) * ws
+            sig = score_fn_torch.scores_from_xiters(flat, torch.from_numpy(off).to(flat.device), ws // tokens).reshape(-1)
+        else:
+            X = torch.cat([flat[i * stride: i * stride + r * ws].view(r, ws) for i, r in zip(act.tolist(), rows)])
+            sig = score_fn_torch(X.view(-1, tokens, ws // tokens).to(torch.float32)).reshape(-1)
         vec = torch.where(sig > C, 1.0, torch.where(sig < 1 - C, 0.0, -1.0)).to(torch.float64).cpu().numpy()   # deter_fix_2
         t2 = time.perf_counter()
         t["policy"] += t2 - t1

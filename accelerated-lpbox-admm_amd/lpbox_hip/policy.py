@@ -180,7 +180,7 @@ class FusedEarlyFixPolicy:
             wq, wk, wv = L["w_qkv"][:, :EMBED], L["w_qkv"][:, EMBED:2 * EMBED], L["w_qkv"][:, 2 * EMBED:]
             for half in range(2):
                 c = slice(64 * half, 64 * half + 64)                            # heads 4 half .. 4 half + 3
-                frags.append(_pack_fragments(torch.cat([wq[:, c], wk[:, c], wv[:, c]], dim=1)))
+                frags.append(_pack_fragments(torch.cat([wq[:, c] * 0.25, wk[:, c], wv[:, c]], dim=1)))   # 1/sqrt(16) folded into Q (exact)
             frags.append(_pack_fragments(L["w_o"]))
             for c in range(4):
                 frags.append(_pack_fragments(L["w1"][:, 128 * c:128 * c + 128]))

@@ -41,3 +41,18 @@ def test_batched_device_loop_matches_per_instance_oracle():
         ro = l2f.run_l2f(o, _last_iterate, ws=100)
         assert res["objective"][i] == ro["objective"] and res["infeasible"][i] == ro["infeasible"], i
         assert bits_equal(b.get_x_sol(i).ravel(), o.get_x_sol().ravel()), i
+
+
+def test_batched_loop_with_fused_policy_runs_and_matches_unfused_decisions():
+    """The fused encoder inside the loop: same windows / fixed sets as the fp32 torch evaluation of the same weights wherever the
+    scores are not within 1e-3 of a threshold (fp16 operands); with reference-style initial weights nothing gets near one."""
+    import torch
+    from lpbox_hip.policy import EarlyFixPolicy, FusedEarlyFixPolicy, random_state
+    sd = random_state(20, seed=0)
+    insts = lp_instances("lp_100_500_seed0.npz")[:4]
+    res = []
+    for pol in (FusedEarlyFixPolicy(sd, tokens=20), EarlyFixPolicy(sd, tokens=20, device="cuda")):
+        b = LpBatch(insts)
+        b.solve_init()
+        res.append(l2f.run_l2f_batch(b, pol, ws=100, max_iter=1000))
+    assert res[0]["windows"] == res[1]["windows"] and np.array_equal(res[0]["objective"], res[1]["objective"])

@@ -10,8 +10,9 @@ from lpbox_hip.policy import EarlyFixPolicy
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 mode = sys.argv[2] if len(sys.argv) > 2 else "net"
 insts = load_instances(FIXTURE)[:B]
-pol = EarlyFixPolicy.random(tokens=20, seed=0, device="cuda", dtype=torch.bfloat16 if mode == "bf16" else torch.float32)
-score = pol if mode in ("net", "bf16") else (lambda x: x[:, -1, -1])          # "last": confident where the newest iterate is near 0/1
+from lpbox_hip.policy import FusedEarlyFixPolicy
+pol = FusedEarlyFixPolicy.random(tokens=20, seed=0) if mode == "fused" else EarlyFixPolicy.random(tokens=20, seed=0, device="cuda", dtype=torch.bfloat16 if mode == "bf16" else torch.float32)
+score = pol if mode in ("net", "bf16", "fused") else (lambda x: x[:, -1, -1])          # "last": confident where the newest iterate is near 0/1
 for rep in range(2):
     b = LpBatch(insts); b.solve_init(); tm = {}
     torch.cuda.synchronize(); t0 = time.perf_counter()
