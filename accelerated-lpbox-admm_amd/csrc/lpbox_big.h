@@ -29,6 +29,8 @@ struct BigState {
     int rhoUpdated, hist_n, iter, iter_start, iter_end, have_prev, halt, stop, ret;
     int pcg_k, pcg_done, pcg_first, phase;
     int pcg_total, outer_total, last_pcg, plain_iter_p1, pcg_max, expr_ready;
+    int l2f, cc, n_live_lo, n_live_hi;      // l2f window semantics (LPcpp:1098-1574); x_iters column; live variables (all ranks), 2 x 31 bits
+    double sum_fix_obj, fix_obj, prev_sum, prev_obj;
     int pad0;
 };
 
@@ -39,6 +41,10 @@ struct BigDev {
     const int *rptr, *rcol, *cptr, *crow;
     double *x, *y1, *y2, *z1, *z2, *b, *pd, *dinv, *rhs, *r, *z, *tmp, *p0, *p1, *gsrc;   // local n-vectors
     double *y3, *z4, *f, *fy, *Ex, *q;    // replicated l-vectors (q doubles as the all-reduce buffer of E*v)
+    double *xt;                           // PCG iterate (committed to x for the live variables after the PCG)
+    uint8_t *live;                        // 1 live, 0 fixed (x holds the fixed value)
+    const uint8_t *newfix;                // this call's fix request: 0 none, 1 -> 0.0, 2 -> 1.0
+    double *xhist; int ws_cap;            // x_iters staging [ws_cap][n_loc]
     double *part;                         // [BIG_NPART][G] workgroup partials
     double *red;                          // [BIG_NPART] reduced scalars (all-reduced over the ranks)
     BigState *st;                         // st[0], st[1]
@@ -47,7 +53,11 @@ struct BigDev {
 // launch helpers (lpbox_big_kernels.hip); every state-carrying launch reads st[*parity], writes st[*parity^1], flips *parity
 hipError_t big_launch_init(const BigDev &d, double c1, hipStream_t s);      // state, x = 1, partial b.x0 -> red[0]
 hipError_t big_launch_init2(const BigDev &d, hipStream_t s);               // best_bin_obj = red[0] (after the all-reduce)
-hipError_t big_launch_set_window(const BigDev &d, int iter_start, int iter_end, int *parity, hipStream_t s);
+hipError_t big_launch_set_window(const BigDev &d, int iter_start, int iter_end, int l2f, int *parity, hipStream_t s);
+hipError_t big_launch_fix1(const BigDev &d, hipStream_t s);                          // gsrc = newly fixed values, partial b.x2 (:1237)
+hipError_t big_launch_fix2(const BigDev &d, int *parity, hipStream_t s);              // f -= E2 x2 (:1278), mask, partial |x_live|^2
+hipError_t big_launch_fix3(const BigDev &d, long n_live_new, double c1_new, int *parity, hipStream_t s);   // state + update_expression (:1329)
+hipError_t big_launch_pack_xiters(const BigDev &d, const int *live_idx, int rows, int ws, double *out, hipStream_t s);
 hipError_t big_launch_prep(const BigDev &d, int do_prep, int *parity, hipStream_t s);
 hipError_t big_launch_fin(const BigDev &d, int nv, hipStream_t s);                    // partials -> red[0..nv)
 hipError_t big_launch_y(const BigDev &d, int *parity, hipStream_t s);                 // y1, y2, refresh, rhs base, y3 (all rows)

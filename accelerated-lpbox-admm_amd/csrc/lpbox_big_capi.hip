@@ -39,7 +39,13 @@ struct lpbox_big {
     bool adaptive = true;
     double kernel_ms = 0.0; long long launches = 0, collectives = 0;
     Buf<int> d_rptr, d_rcol, d_cptr, d_crow;
-    Buf<double> x, y1, y2, z1, z2, db, pd, dinv, rhs, r, z, tmp, p0, p1, gsrc, y3, z4, df, fy, Ex, q, part, red;
+    Buf<double> x, y1, y2, z1, z2, db, pd, dinv, rhs, r, z, tmp, p0, p1, gsrc, y3, z4, df, fy, Ex, q, part, red, xt, xhist, xi_out;
+    Buf<uint8_t> live, newfix;
+    Buf<int> d_live_idx;
+    std::vector<int> left_idx, xi_left;   // local indices of the live variables (now / as of the last l2f window)
+    long n_live_glob = 0;                 // live variables over all ranks
+    int ws_cap = 0, xi_rows = 0;
+    bool xi_valid = false;
     double *ext_q = nullptr, *ext_red = nullptr;     // caller-owned exchange buffers (e.g. torch tensors), optional
     Buf<BigState> st;
     BigState hst;
@@ -50,6 +56,7 @@ struct lpbox_big {
         d.rptr = d_rptr.p; d.rcol = d_rcol.p; d.cptr = d_cptr.p; d.crow = d_crow.p;
         d.x = x.p; d.y1 = y1.p; d.y2 = y2.p; d.z1 = z1.p; d.z2 = z2.p; d.b = db.p; d.pd = pd.p; d.dinv = dinv.p; d.rhs = rhs.p;
         d.r = r.p; d.z = z.p; d.tmp = tmp.p; d.p0 = p0.p; d.p1 = p1.p; d.gsrc = gsrc.p;
+        d.xt = xt.p; d.live = live.p; d.newfix = newfix.p; d.xhist = xhist.p; d.ws_cap = ws_cap;
         d.y3 = y3.p; d.z4 = z4.p; d.f = df.p; d.fy = fy.p; d.Ex = Ex.p; d.q = ext_q ? ext_q : q.p; d.part = part.p; d.red = ext_red ? ext_red : red.p; d.st = st.p;
         return d;
     }
@@ -133,9 +140,9 @@ void lpbox_big_destroy(lpbox_big_t *h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->d_rptr.release(); h->d_rcol.release(); h->d_cptr.release(); h->d_crow.release();
     for (Buf<double> *bp : {&h->x, &h->y1, &h->y2, &h->z1, &h->z2, &h->db, &h->pd, &h->dinv, &h->rhs, &h->r, &h->z, &h->tmp, &h->p0, &h->p1,
-                            &h->gsrc, &h->y3, &h->z4, &h->df, &h->fy, &h->Ex, &h->q, &h->part, &h->red})
+                            &h->gsrc, &h->y3, &h->z4, &h->df, &h->fy, &h->Ex, &h->q, &h->part, &h->red, &h->xt, &h->xhist, &h->xi_out})
         bp->release();
-    h->st.release();
+    h->st.release(); h->live.release(); h->newfix.release(); h->d_live_idx.release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -202,8 +209,10 @@ int lpbox_big_init(lpbox_big_t *h) {
         if (!h->stream) { HIPCHK(hipStreamCreate(&h->stream)); h->own_stream = true; }
         HIPCHK(hipEventCreate(&h->ev0)); HIPCHK(hipEventCreate(&h->ev1));
         HIPCHK(h->d_rptr.alloc((size_t)l + 1)); HIPCHK(h->d_rcol.alloc(h->nnz)); HIPCHK(h->d_cptr.alloc((size_t)n + 1)); HIPCHK(h->d_crow.alloc(h->nnz));
-        for (Buf<double> *bp : {&h->x, &h->y1, &h->y2, &h->z1, &h->z2, &h->db, &h->pd, &h->dinv, &h->rhs, &h->r, &h->z, &h->tmp, &h->p0, &h->p1, &h->gsrc})
+        for (Buf<double> *bp : {&h->x, &h->y1, &h->y2, &h->z1, &h->z2, &h->db, &h->pd, &h->dinv, &h->rhs, &h->r, &h->z, &h->tmp, &h->p0, &h->p1, &h->gsrc, &h->xt})
             HIPCHK(bp->alloc(n));
+        HIPCHK(h->live.alloc(n)); HIPCHK(h->newfix.alloc(n)); HIPCHK(h->d_live_idx.alloc(n));
+        HIPCHK(hipMemset(h->newfix.p, 0, (size_t)n));
         for (Buf<double> *bp : {&h->y3, &h->z4, &h->df, &h->fy, &h->Ex, &h->q}) HIPCHK(bp->alloc(l));
         HIPCHK(h->part.alloc((size_t)BIG_NPART * h->G)); HIPCHK(h->red.alloc(BIG_NPART)); HIPCHK(h->st.alloc(2));
         HIPCHK(hipMemcpy(h->d_rptr.p, h->rptr.data(), sizeof(int) * ((size_t)l + 1), hipMemcpyHostToDevice));
@@ -216,6 +225,9 @@ int lpbox_big_init(lpbox_big_t *h) {
         h->uploaded = true;
     }
     HIPCHK(hipMemcpyAsync(h->df.p, h->f.data(), sizeof(double) * (size_t)h->l, hipMemcpyHostToDevice, h->stream));
+    h->left_idx.resize(h->n_loc);
+    for (int j = 0; j < h->n_loc; j++) h->left_idx[j] = j;
+    h->n_live_glob = h->n_glob; h->xi_valid = false;
     const BigDev d = h->dev();
     h->parity = 0;
     HIPCHK(big_launch_init(d, std::pow((double)h->n_glob, 1.0 / 2), h->stream));   // pow(n, 1/p), p = 2 (LPcpp:427,503), n = ALL variables
@@ -228,12 +240,7 @@ int lpbox_big_init(lpbox_big_t *h) {
     return 1;
 }
 
-int lpbox_big_iterate(lpbox_big_t *h, int iter_start, int iter_end, int *ret) {     // ADMM_lp_iters LPcpp:766-1095
-    if (!h) return lpbox_fail(LPBOX_E_BADHANDLE, "bad handle");
-    if (!h->inited) return lpbox_fail(LPBOX_E_STATE, "solve_init has not been called");
-    CHK(use_device(h));
-    const BigDev d = h->dev();
-    HIPCHK(big_launch_set_window(d, iter_start, iter_end, &h->parity, h->stream));
+static int run_window(lpbox_big *h, const BigDev &d, int iter_end) {
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     for (;;) {
         CHK(read_state(h));
@@ -258,7 +265,118 @@ int lpbox_big_iterate(lpbox_big_t *h, int iter_start, int iter_end, int *ret) { 
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     h->kernel_ms += ms;
+    return LPBOX_OK;
+}
+
+int lpbox_big_iterate(lpbox_big_t *h, int iter_start, int iter_end, int *ret) {     // ADMM_lp_iters LPcpp:766-1095
+    if (!h) return lpbox_fail(LPBOX_E_BADHANDLE, "bad handle");
+    if (!h->inited) return lpbox_fail(LPBOX_E_STATE, "solve_init has not been called");
+    CHK(use_device(h));
+    const BigDev d = h->dev();
+    HIPCHK(big_launch_set_window(d, iter_start, iter_end, 0, &h->parity, h->stream));
+    CHK(run_window(h, d, iter_end));
     if (ret) *ret = h->hst.ret;
+    return LPBOX_OK;
+}
+
+// ADMM_lp_iters_l2f (LPcpp:1098-1574).  vec_local: this rank's slice of the fix vector, one entry per LOCAL live variable in
+// ascending order (1 / 0 = fix, anything else = leave); num_global: fixes over all ranks (the caller sums the local counts).
+int lpbox_big_iterate_l2f(lpbox_big_t *h, int iter_start, int iter_end, const double *vec_local, long num_global, int *ret) {
+    if (!h) return lpbox_fail(LPBOX_E_BADHANDLE, "bad handle");
+    if (!h->inited) return lpbox_fail(LPBOX_E_STATE, "solve_init has not been called");
+    const int ws = iter_end - iter_start;
+    if (ws > LP_XITERS_COLS) return lpbox_fail(LPBOX_E_BADARG, "window of %d iterations exceeds the %d columns of x_iters (LPcpp:1113)", ws, LP_XITERS_COLS);
+    if (num_global < 0 || num_global > h->n_live_glob) return lpbox_fail(LPBOX_E_BADARG, "fix count %ld outside [0,%ld]", num_global, h->n_live_glob);
+    CHK(use_device(h));
+    const int n_live_loc = (int)h->left_idx.size();
+    std::vector<uint8_t> nf;
+    if (num_global != 0) {
+        if (!vec_local && n_live_loc) return lpbox_fail(LPBOX_E_BADARG, "fix vector missing");
+        nf.assign(h->n_loc, 0);
+        std::vector<int> keep; keep.reserve(n_live_loc);
+        long cnt = 0;
+        for (int q = 0; q < n_live_loc; q++) {
+            const int j = h->left_idx[q];
+            if (vec_local[q] == 1) { nf[j] = 2; cnt++; } else if (vec_local[q] == 0) { nf[j] = 1; cnt++; } else keep.push_back(j);
+        }
+        if (h->world == 1 && cnt != num_global) return lpbox_fail(LPBOX_E_BADARG, "vec fixes %ld variables but num = %ld", cnt, num_global);
+        if (cnt > num_global) return lpbox_fail(LPBOX_E_BADARG, "this rank fixes %ld variables, more than the global count %ld", cnt, num_global);
+        h->left_idx.swap(keep);
+    }
+    if (ws > 0 && (h->ws_cap < ws || !h->xhist.p)) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(h->xhist.alloc((size_t)ws * h->n_loc));
+        h->ws_cap = ws;
+    }
+    const BigDev d = h->dev();
+    HIPCHK(big_launch_set_window(d, iter_start, iter_end, 1, &h->parity, h->stream));
+    if (num_global != 0) {
+        const long n_live_new = h->n_live_glob - num_global;
+        HIPCHK(hipMemcpyAsync(h->newfix.p, nf.data(), nf.size(), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(big_launch_fix1(d, h->stream)); h->launches++;
+        FIN(1);                                                                     // fix_obj = b2.x2
+        ROWS(0);                                                                    // q = E2 * x2
+        HIPCHK(big_launch_fix2(d, &h->parity, h->stream)); h->launches++;
+        FIN(1);                                                                     // |x_live|^2
+        HIPCHK(big_launch_fix3(d, n_live_new, std::pow((double)n_live_new, 1.0 / 2), &h->parity, h->stream)); h->launches++;
+        if (n_live_new != 0) {
+            ROWS(0);                                                                // E * x (live columns) for the first y3
+            HIPCHK(big_launch_z4(d, 1, &h->parity, h->stream)); h->launches++;
+        }
+        HIPCHK(hipMemsetAsync(h->newfix.p, 0, (size_t)h->n_loc, h->stream));
+        h->n_live_glob = n_live_new;
+    }
+    h->xi_left = h->left_idx; h->xi_rows = (int)h->left_idx.size();
+    if (ws > 0) HIPCHK(hipMemsetAsync(h->xhist.p, 0, sizeof(double) * (size_t)ws * h->n_loc, h->stream));   // x_iters = Zero (:1113)
+    if (h->xi_rows) HIPCHK(hipMemcpyAsync(h->d_live_idx.p, h->xi_left.data(), sizeof(int) * (size_t)h->xi_rows, hipMemcpyHostToDevice, h->stream));
+    CHK(run_window(h, d, iter_end));        // synchronises: nf / xi_left stay alive until here
+    h->xi_valid = true;
+    if (ret) *ret = h->hst.ret;
+    return LPBOX_OK;
+}
+
+int lpbox_big_get_n(lpbox_big_t *h) {                                               // live variables of this rank
+    if (!h || !h->inited) return lpbox_fail(LPBOX_E_STATE, "not initialised");
+    return (int)h->left_idx.size();
+}
+
+// (rows x ws) row-major x_iters of this rank's live variables, left on the device; rows = live variables when the window started
+int lpbox_big_get_x_iters_device(lpbox_big_t *h, int ws, void **dev_ptr, int *rows) {
+    if (!h || !h->inited) return lpbox_fail(LPBOX_E_STATE, "not initialised");
+    if (!h->xi_valid) return lpbox_fail(LPBOX_E_STATE, "solve_iter_l2f has not been called");
+    if (ws <= 0 || ws > LP_XITERS_COLS) return lpbox_fail(LPBOX_E_BADARG, "ws = %d outside (0,%d]", ws, LP_XITERS_COLS);
+    CHK(use_device(h));
+    const size_t need = (size_t)std::max(h->xi_rows, 1) * ws;
+    if (h->xi_out.count < need) { HIPCHK(hipStreamSynchronize(h->stream)); HIPCHK(h->xi_out.alloc(need)); }
+    HIPCHK(big_launch_pack_xiters(h->dev(), h->d_live_idx.p, h->xi_rows, ws, h->xi_out.p, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (dev_ptr) *dev_ptr = h->xi_out.p;
+    if (rows) *rows = h->xi_rows;
+    return LPBOX_OK;
+}
+
+int lpbox_big_get_x_iters(lpbox_big_t *h, int ws, double *out) {
+    void *p = nullptr; int rows = 0;
+    if (!out) { if (!h || !h->xi_valid) return lpbox_fail(LPBOX_E_STATE, "solve_iter_l2f has not been called"); return h->xi_rows; }
+    CHK(lpbox_big_get_x_iters_device(h, ws, &p, &rows));
+    if (rows) HIPCHK(hipMemcpy(out, p, sizeof(double) * (size_t)rows * ws, hipMemcpyDeviceToHost));
+    return rows;
+}
+
+// binary solution of this rank's variables: fixed ones at their value, live ones rounded (get_x_sol, LPcpp:1648-1666)
+int lpbox_big_get_x_sol(lpbox_big_t *h, double *out_local) {
+    if (!h || !h->inited || !out_local) return lpbox_fail(LPBOX_E_STATE, "not initialised");
+    CHK(use_device(h));
+    std::vector<uint8_t> lv(h->n_loc);
+    HIPCHK(hipMemcpy(out_local, h->x.p, sizeof(double) * (size_t)h->n_loc, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(lv.data(), h->live.p, (size_t)h->n_loc, hipMemcpyDeviceToHost));
+    for (int j = 0; j < h->n_loc; j++) if (lv[j]) out_local[j] = out_local[j] >= 0.5 ? 1.0 : 0.0;
+    return h->n_loc;
+}
+
+int lpbox_big_cal_obj(lpbox_big_t *h, double *out) {                                // cal_Obj, LPcpp:1630-1642
+    if (!h || !h->inited || !out) return lpbox_fail(LPBOX_E_STATE, "not initialised");
+    *out = h->n_live_glob != 0 ? h->hst.sum_fix_obj + h->hst.cur_obj : h->hst.sum_fix_obj;
     return LPBOX_OK;
 }
 
@@ -274,7 +392,8 @@ int lpbox_big_get_vec(lpbox_big_t *h, const char *name, double *out, long cap) {
     CHK(use_device(h));
     const double *src = nullptr; long len = h->n_loc;
     if (!strcmp(name, "x")) src = h->x.p; else if (!strcmp(name, "z1")) src = h->z1.p; else if (!strcmp(name, "z2")) src = h->z2.p;
-    else if (!strcmp(name, "pd")) src = h->pd.p;
+    else if (!strcmp(name, "pd")) src = h->pd.p; else if (!strcmp(name, "b")) src = h->db.p;
+    else if (!strcmp(name, "f")) { src = h->df.p; len = h->l; }
     else if (!strcmp(name, "z4")) { src = h->z4.p; len = h->l; } else if (!strcmp(name, "Ex")) { src = h->Ex.p; len = h->l; }
     else return lpbox_fail(LPBOX_E_BADARG, "unknown vector '%s'", name);
     if (cap < len) return lpbox_fail(LPBOX_E_BADARG, "buffer too small");
@@ -289,6 +408,7 @@ int lpbox_big_get_scalar(lpbox_big_t *h, const char *name, double *out) {
         {"rho1", s.rho1}, {"rho4", s.rho4}, {"gamma", s.gamma_val}, {"dI", s.dI}, {"rho4Et", s.r4Et}, {"std_obj", s.std_obj},
         {"cur_obj", s.cur_obj}, {"best_bin_obj", s.best_bin_obj}, {"cvg1", s.cvg1}, {"cvg2", s.cvg2}, {"obj_val", s.obj_val},
         {"iter", (double)s.iter}, {"outer_total", (double)s.outer_total}, {"pcg_total", (double)s.pcg_total}, {"last_pcg", (double)s.last_pcg},
+        {"sum_fix_obj", s.sum_fix_obj}, {"fix_obj", s.fix_obj}, {"c1", s.c1}, {"ret", (double)s.ret}, {"n_live", (double)h->n_live_glob},
         {"stop", (double)s.stop}, {"plain_iter_p1", (double)s.plain_iter_p1}, {"kmax", (double)h->kmax},
         {"launches", (double)h->launches}, {"collectives", (double)h->collectives}, {"kernel_ms", h->kernel_ms},
         {"threads", (double)BIG_T}, {"chunk", (double)(BIG_T * h->EPT)}, {"groups", (double)h->G},

@@ -10,6 +10,7 @@
 #include "lpbox_dev_common.h"
 
 #include <float.h>
+#include <algorithm>
 
 namespace {
 
@@ -51,7 +52,7 @@ __global__ void __launch_bounds__(T) big_k_init(BigDev d, double c1) {          
         double c = 0.0;
         if (j < d.n_loc) {
             d.x[j] = 1.0; d.z1[j] = 0.0; d.z2[j] = 0.0; d.pd[j] = 0.0; d.dinv[j] = 1.0;   // :583-586, :616-617
-            d.y1[j] = 1.0; d.y2[j] = 1.0; d.gsrc[j] = 1.0;
+            d.y1[j] = 1.0; d.y2[j] = 1.0; d.gsrc[j] = 1.0; d.xt[j] = 1.0; d.live[j] = 1;
             d.r[j] = 0.0; d.z[j] = 0.0; d.tmp[j] = 0.0; d.p0[j] = 0.0; d.p1[j] = 0.0; d.rhs[j] = 0.0;
             c = d.b[j] * 1.0;                                                    // best_bin_obj = b.dot(x0) (:727)
         }
@@ -67,6 +68,7 @@ __global__ void __launch_bounds__(T) big_k_init(BigDev d, double c1) {          
         memset(s, 0, sizeof(BigState));
         s->rho1 = s->rho2 = s->rho4 = s->prev_rho1 = s->prev_rho2 = s->prev_rho4 = LP_RHO0;   // :623-630
         s->gamma_val = LP_GAMMA0; s->std_obj = 1.0; s->rhoUpdated = 1; s->c1 = c1;
+        s->n_live_lo = (int)(d.n_glob & 0x7fffffff); s->n_live_hi = (int)(d.n_glob >> 31);
         d.st[1] = d.st[0];
     }
 }
@@ -76,10 +78,11 @@ __global__ void big_k_init2(BigDev d) {       // after the partial of b.x0 has b
     d.st[1].best_bin_obj = d.red[0];
 }
 
-__global__ void big_k_set_window(BigDev d, int in, int out, int iter_start, int iter_end) {
+__global__ void big_k_set_window(BigDev d, int in, int out, int iter_start, int iter_end, int l2f) {
     d.st[out] = d.st[in];
     BigState *s = d.st + out;
     s->iter = iter_start; s->iter_start = iter_start; s->iter_end = iter_end; s->ret = 0; s->stop = LP_STOP_NONE; s->halt = BIG_HALT_NONE;
+    s->l2f = l2f; s->cc = 0;
 }
 
 __global__ void big_k_resume(BigDev d, int in, int out, int reset_pcg_max) {
@@ -108,7 +111,8 @@ __global__ void __launch_bounds__(T) big_k_prep(BigDev d, int in, int out, int d
             const double t0 = (xn < 2.2204e-16) ? 2.2204e-16 : xn;
             s->cvg1 = sqrt(d.red[1]) / t0; s->cvg2 = sqrt(d.red[2]) / t0;      // :931-933
             bool stopped = false;
-            if (s->cvg1 <= LP_STOP_THRESHOLD && s->cvg2 <= LP_STOP_THRESHOLD && it != s->iter_start) {   // :934 (plain loop: ret stays 0)
+            if (s->cvg1 <= LP_STOP_THRESHOLD && s->cvg2 <= LP_STOP_THRESHOLD && (s->l2f || it != s->iter_start)) {   // :934 / :1503
+                if (s->l2f) s->ret = 1;                                          // :1505 (plain loop: ret stays 0)
                 s->stop = LP_STOP_Y1Y2; stopped = true;
             } else {
                 if ((it + 1) % LP_RHO_STEP == 0) {                                // :951-970
@@ -151,7 +155,7 @@ __global__ void __launch_bounds__(T) big_k_prep(BigDev d, int in, int out, int d
     for (int q = 0; q < d.EPT; q++) {
         const int j = blockIdx.x * (T * d.EPT) + q * T + threadIdx.x;
         double c = 0.0;
-        if (j < d.n_loc) { const double u = (d.x[j] + d.z2[j] / rho2) - 0.5; c = u * u; }
+        if (j < d.n_loc && d.live[j]) { const double u = (d.x[j] + d.z2[j] / rho2) - 0.5; c = u * u; }
         pa[0] = pa[0] + c;
     }
     store_partials<1>(d, pa, red, parity);
@@ -186,7 +190,7 @@ __global__ void __launch_bounds__(T) big_k_y(BigDev d, int in, int out) {
             d.pd[j] = pd;
             if (rhoUpdated) d.dinv[j] = (pd != 0.0) ? 1.0 / pd : 1.0;            // :883-890
             d.rhs[j] = (rho1 * y1 + rho2 * y2) - ((d.b[j] + z1) + z2);            // :872
-            d.gsrc[j] = y1;                                                       // x_sol = y1 (:892)
+            d.gsrc[j] = d.live[j] ? y1 : 0.0;                                     // x_sol = y1 (:892); fixed columns are gone from E
         }
     if (blockIdx.x < d.Gl)
         for (int q = 0; q < d.EPTl; q++) {
@@ -293,8 +297,9 @@ __global__ void __launch_bounds__(T) big_k_resid(BigDev d, int in, int out) {   
             const double rhs = d.rhs[j];
             const double r = rhs - Mx;
             const double p = d.dinv[j] * r;
-            d.x[j] = y1; d.r[j] = r; d.p0[j] = p;
-            c0 = rhs * rhs; c1 = r * r; c2 = r * p;
+            const bool lv = d.live[j];
+            d.xt[j] = y1; d.r[j] = r; d.p0[j] = lv ? p : 0.0;
+            if (lv) { c0 = rhs * rhs; c1 = r * r; c2 = r * p; }
         }
         pb[0] = pb[0] + c0; pb[1] = pb[1] + c1; pb[2] = pb[2] + c2;
     }
@@ -309,7 +314,7 @@ __global__ void __launch_bounds__(T) big_k_pcg_cols(BigDev d, int in, int out) {
     if (si->halt || si->phase != 2) { forward_state(d, in, out); return; }
     if (si->pcg_done) {
         if (si->pcg_first)                                                       // rhs == 0: x := 0 (:273-278)
-            for (int q = 0; q < d.EPT; q++) { const int j = blockIdx.x * (T * d.EPT) + q * T + threadIdx.x; if (j < d.n_loc) d.x[j] = 0.0; }
+            for (int q = 0; q < d.EPT; q++) { const int j = blockIdx.x * (T * d.EPT) + q * T + threadIdx.x; if (j < d.n_loc) d.xt[j] = 0.0; }
         if (LEADER) { d.st[out] = *si; d.st[out].pcg_first = 0; }
         return;
     }
@@ -333,7 +338,7 @@ __global__ void __launch_bounds__(T) big_k_pcg_cols(BigDev d, int in, int out) {
             Mp += dI * (1.0 * pj);
             Mp += t;
             d.tmp[j] = Mp;
-            c = pj * Mp;
+            c = d.live[j] ? pj * Mp : 0.0;
         }
         pc[0] = pc[0] + c;
     }
@@ -358,12 +363,13 @@ __global__ void __launch_bounds__(T) big_k_pcg_upd(BigDev d, int in, int out) { 
             const int j = blockIdx.x * (T * d.EPT) + q * T + threadIdx.x;
             double a = 0.0, b2 = 0.0;
             if (j < d.n_loc) {
-                double x = d.x[j], r = d.r[j];
+                double x = d.xt[j], r = d.r[j];
                 x += alpha * p[j];
                 r -= alpha * d.tmp[j];
                 const double z = d.dinv[j] * r;
-                d.x[j] = x; d.r[j] = r; d.z[j] = z;
-                a = r * r; b2 = r * z;
+                const bool lv = d.live[j];
+                d.xt[j] = x; d.r[j] = r; d.z[j] = lv ? z : 0.0;
+                if (lv) { a = r * r; b2 = r * z; }
             }
             pd2[0] = pd2[0] + a; pd2[1] = pd2[1] + b2;
         }
@@ -388,18 +394,26 @@ __global__ void __launch_bounds__(T) big_k_post(BigDev d, int in, int out) {
             return;
         }
     }
+    if (si->l2f && si->stop == LP_STOP_PCG) {   // alpha < 0 inside the l2f loop: return 1, x_sol untouched (:1450-1454)
+        if (LEADER) { d.st[out] = *si; BigState *s = d.st + out; s->ret = 1; s->halt = BIG_HALT_STOP; s->pcg_done = 1; s->last_pcg = k; s->pcg_total += k; }
+        return;
+    }
     const double g1 = si->gamma_val * si->rho1, g2 = si->gamma_val * si->rho2;
+    double *xh = (si->l2f && d.xhist && si->cc < d.ws_cap) ? d.xhist + (size_t)si->cc * d.n_loc : nullptr;
     double e5[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     for (int q = 0; q < d.EPT; q++) {
         const int j = blockIdx.x * (T * d.EPT) + q * T + threadIdx.x;
         double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0, v4 = 0.0;
         if (j < d.n_loc) {
-            const double x = d.x[j], y1 = d.y1[j], y2 = d.y2[j], b = d.b[j];
+            const bool lv = d.live[j];
+            const double x = lv ? d.xt[j] : d.x[j], y1 = d.y1[j], y2 = d.y2[j], b = d.b[j];   // commit: fixed variables keep their value
+            d.x[j] = x;
+            if (xh) xh[j] = x;                                                // x_iters column (:1472-1475)
             d.z1[j] = d.z1[j] + g1 * (x - y1);
             d.z2[j] = d.z2[j] + g2 * (x - y2);
-            d.gsrc[j] = x;
+            d.gsrc[j] = lv ? x : 0.0;
             const double d1 = x - y1, d2 = x - y2, xb = x >= 0.5 ? 1.0 : 0.0;
-            v0 = x * x; v1 = d1 * d1; v2 = d2 * d2; v3 = b * x; v4 = b * xb;
+            if (lv) { v0 = x * x; v1 = d1 * d1; v2 = d2 * d2; v3 = b * x; v4 = b * xb; }
         }
         e5[0] = e5[0] + v0; e5[1] = e5[1] + v1; e5[2] = e5[2] + v2; e5[3] = e5[3] + v3; e5[4] = e5[4] + v4;
     }
@@ -408,6 +422,7 @@ __global__ void __launch_bounds__(T) big_k_post(BigDev d, int in, int out) {
         d.st[out] = *si;
         BigState *s = d.st + out;
         s->pcg_done = 1; s->last_pcg = k; s->pcg_total += k; s->outer_total++;
+        if (si->l2f) s->cc = si->cc + 1;
         if (k > s->pcg_max) s->pcg_max = k;
         s->phase = 3;
     }
@@ -423,7 +438,7 @@ __global__ void __launch_bounds__(T) big_k_z4(BigDev d, int in, int out, int ini
     }
     if (si->halt || si->phase != 3) { forward_state(d, in, out); return; }
     const double g4 = si->gamma_val * si->rho4;
-    const bool overwrite = si->iter == si->iter_start;
+    const bool overwrite = !si->l2f && si->iter == si->iter_start;
     for (int s = 0; s < d.EPTl; s++) {
         const int i = blockIdx.x * (T * d.EPTl) + s * T + threadIdx.x;
         if (i >= d.l) continue;
@@ -433,6 +448,88 @@ __global__ void __launch_bounds__(T) big_k_z4(BigDev d, int in, int out, int ini
         d.z4[i] = overwrite ? dd : d.z4[i] + dd;
     }
     if (LEADER) { d.st[out] = *si; d.st[out].have_prev = 1; d.st[out].phase = 0; }
+}
+
+// ---- early fixing (LPcpp:1124-1335) as a mask; three passes cut at the two reductions it needs ----
+__global__ void __launch_bounds__(T) big_k_fix1(BigDev d) {          // x2 = the newly fixed values; partial fix_obj = b2.x2 (:1237)
+    __shared__ double red[2 * RED_MAXV * RED_MAXW];
+    int parity = 0;
+    double pf[1] = {0.0};
+    for (int q = 0; q < d.EPT; q++) {
+        const int j = blockIdx.x * (T * d.EPT) + q * T + threadIdx.x;
+        double c = 0.0;
+        if (j < d.n_loc) {
+            const int nf = d.newfix[j];
+            const double val = nf == 2 ? 1.0 : 0.0;
+            d.gsrc[j] = nf ? val : 0.0;
+            if (nf) c = d.b[j] * val;
+        }
+        pf[0] = pf[0] + c;
+    }
+    store_partials<1>(d, pf, red, parity);
+}
+
+__global__ void __launch_bounds__(T) big_k_fix2(BigDev d, int in, int out) {   // red[0] = fix_obj, q = E2*x2 (all ranks)
+    __shared__ double red[2 * RED_MAXV * RED_MAXW];
+    int parity = 0;
+    if (blockIdx.x < d.Gl)
+        for (int s = 0; s < d.EPTl; s++) {
+            const int i = blockIdx.x * (T * d.EPTl) + s * T + threadIdx.x;
+            if (i < d.l) d.f[i] = d.f[i] - d.q[i];                                  // f1 = f - E2*x2 (:1278)
+        }
+    if (LEADER) { d.st[out] = d.st[in]; d.st[out].fix_obj = d.red[0]; }
+    if (blockIdx.x >= d.G) return;
+    double px[1] = {0.0};
+    for (int q = 0; q < d.EPT; q++) {
+        const int j = blockIdx.x * (T * d.EPT) + q * T + threadIdx.x;
+        double c = 0.0;
+        if (j < d.n_loc) {
+            const int nf = d.newfix[j];
+            if (nf) { d.live[j] = 0; d.x[j] = nf == 2 ? 1.0 : 0.0; }
+            else if (d.live[j]) { const double x = d.x[j]; c = x * x; }
+        }
+        px[0] = px[0] + c;
+    }
+    store_partials<1>(d, px, red, parity);
+}
+
+// red[0] = |x_live|^2.  n_live_new == 0: everything is fixed (:1212-1217, nothing else is updated).
+__global__ void __launch_bounds__(T) big_k_fix3(BigDev d, int in, int out, long n_live_new, double c1_new) {
+    const BigState *si = d.st + in;
+    const double rho1 = si->rho1, rho2 = si->rho2, rho4 = si->rho4;
+    if (LEADER) {
+        d.st[out] = *si;
+        BigState *s = d.st + out;
+        s->n_live_lo = (int)(n_live_new & 0x7fffffff); s->n_live_hi = (int)(n_live_new >> 31);
+        if (n_live_new == 0) { s->ret = 1; s->stop = LP_STOP_ALLFIXED; s->halt = BIG_HALT_STOP; }
+        else {
+            if (sqrt(d.red[0]) < 1e-3) s->ret = 1;                                 // :1223
+            s->prev_sum = s->sum_fix_obj; s->sum_fix_obj += s->fix_obj; s->prev_obj = s->cur_obj;   // :1247-1250
+            s->c1 = c1_new;
+            double dI = 0.0; dI += rho1 + rho2;                                      // update_expression (:1329 -> :2289-2404)
+            s->dI = dI; s->r4Et = rho4; s->expr_ready = 1;
+        }
+    }
+    if (n_live_new == 0) return;
+    double dI = 0.0; dI += rho1 + rho2;
+    for (int q = 0; q < d.EPT; q++) {
+        const int j = blockIdx.x * (T * d.EPT) + q * T + threadIdx.x;
+        if (j >= d.n_loc) continue;
+        double pd = dI;
+        pd += rho4 * (double)(d.cptr[j + 1] - d.cptr[j]);
+        d.pd[j] = pd;
+        d.dinv[j] = (pd != 0.0) ? 1.0 / pd : 1.0;        // the preconditioner always mirrors pd (a stale one is UB in the reference)
+        d.gsrc[j] = d.live[j] ? d.x[j] : 0.0;            // for E*x of the first iteration's y3
+    }
+}
+
+// out[r*ws + c] = x after iteration c of the r-th LOCAL live variable (get_x_iters_d, LPcpp:1616-1627)
+__global__ void big_k_pack_xiters(BigDev d, const int *live_idx, int rows, int ws, double *out) {
+    const long total = (long)rows * ws;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(e / ws), c = (int)(e % ws);
+        out[e] = c < d.ws_cap ? d.xhist[(size_t)c * d.n_loc + live_idx[r]] : 0.0;
+    }
 }
 
 }  // namespace
@@ -453,8 +550,21 @@ hipError_t big_launch_init2(const BigDev &d, hipStream_t s) {
     hipLaunchKernelGGL(big_k_init2, dim3(1), dim3(1), 0, s, d);
     return hipGetLastError();
 }
-hipError_t big_launch_set_window(const BigDev &d, int iter_start, int iter_end, int *parity, hipStream_t s) {
-    hipLaunchKernelGGL(big_k_set_window, dim3(1), dim3(1), 0, s, d, *parity, *parity ^ 1, iter_start, iter_end);
+hipError_t big_launch_fix1(const BigDev &d, hipStream_t s) {
+    hipLaunchKernelGGL(big_k_fix1, dim3(d.G), dim3(T), 0, s, d);
+    return hipGetLastError();
+}
+hipError_t big_launch_fix2(const BigDev &d, int *parity, hipStream_t s) { BIG_LAUNCH(big_k_fix2, (d.G > d.Gl ? d.G : d.Gl)); return hipGetLastError(); }
+hipError_t big_launch_fix3(const BigDev &d, long n_live_new, double c1_new, int *parity, hipStream_t s) { BIG_LAUNCH(big_k_fix3, d.G, n_live_new, c1_new); return hipGetLastError(); }
+hipError_t big_launch_pack_xiters(const BigDev &d, const int *live_idx, int rows, int ws, double *out, hipStream_t s) {
+    if (rows <= 0 || ws <= 0) return hipSuccess;
+    const long total = (long)rows * ws;
+    const int grid = (int)std::min<long>((total + 255) / 256, 65535);
+    hipLaunchKernelGGL(big_k_pack_xiters, dim3(grid), dim3(256), 0, s, d, live_idx, rows, ws, out);
+    return hipGetLastError();
+}
+hipError_t big_launch_set_window(const BigDev &d, int iter_start, int iter_end, int l2f, int *parity, hipStream_t s) {
+    hipLaunchKernelGGL(big_k_set_window, dim3(1), dim3(1), 0, s, d, *parity, *parity ^ 1, iter_start, iter_end, l2f);
     *parity ^= 1;
     return hipGetLastError();
 }

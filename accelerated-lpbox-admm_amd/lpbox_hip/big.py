@@ -101,4 +101,60 @@ class BigLp:
         return v.value
 
     def cal_Obj(self):
-        return self.scalar("cur_obj")          # LPcpp:1630-1642 with nothing fixed: sum_fix_obj = 0
+        v = C.c_double()                       # LPcpp:1630-1642
+        check(self._L.lpbox_big_cal_obj(self._h, C.byref(v)), "lpbox_big_cal_obj")
+        return v.value
+
+    # ---- early fixing on the sharded instance (ADMM_lp_iters_l2f, LPcpp:1098-1574) ----
+    def get_n(self):
+        """Live variables of THIS rank."""
+        return check(self._L.lpbox_big_get_n(self._h), "lpbox_big_get_n")
+
+    def solve_iter_l2f(self, i, j, vec_local=None, num_global=0):
+        """vec_local: fix vector over this rank's live variables (1 / 0 fix, -1 leave); num_global: fixes over all ranks
+        (None: count the local ones and sum them over the process group)."""
+        vp = None
+        if vec_local is not None:
+            vec_local = np.ascontiguousarray(vec_local, np.float64).ravel()
+            if vec_local.shape[0] < self.get_n():
+                raise ValueError("fix vector shorter than this rank's live variables")
+            vp = vec_local.ctypes.data_as(C.c_void_p)
+        if num_global is None:
+            k = 0 if vec_local is None else int(np.count_nonzero((vec_local[:self.get_n()] == 1) | (vec_local[:self.get_n()] == 0)))
+            num_global = self.sum_over_ranks(k)
+        ret = C.c_int()
+        check(self._L.lpbox_big_iterate_l2f(self._h, int(i), int(j), vp, int(num_global), C.byref(ret)), "lpbox_big_iterate_l2f")
+        return ret.value
+
+    def sum_over_ranks(self, k):
+        if self.world == 1:
+            return int(k)
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([int(k)], dtype=torch.int64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t)
+        return int(t.item())
+
+    def get_x_iters_2d(self, ws):
+        rows = check(self._L.lpbox_big_get_x_iters(self._h, int(ws), None), "lpbox_big_get_x_iters")
+        out = np.zeros((rows, int(ws)))
+        if rows:
+            check(self._L.lpbox_big_get_x_iters(self._h, int(ws), out.ctypes.data_as(C.c_void_p)), "lpbox_big_get_x_iters")
+        return out
+
+    def x_iters_torch(self, ws):
+        """This rank's (rows x ws) iterate windows as a zero-copy torch CUDA tensor."""
+        import torch
+        ptr, rows = C.c_void_p(), C.c_int()
+        check(self._L.lpbox_big_get_x_iters_device(self._h, int(ws), C.byref(ptr), C.byref(rows)), "lpbox_big_get_x_iters_device")
+        if rows.value == 0:
+            return torch.zeros((0, int(ws)), dtype=torch.float64, device="cuda")
+
+        class _Dev:
+            __cuda_array_interface__ = {"shape": (rows.value * int(ws),), "typestr": "<f8", "data": (ptr.value, False), "version": 2}
+        return torch.as_tensor(_Dev(), device="cuda").view(rows.value, int(ws))
+
+    def local_x_sol(self):
+        out = np.zeros(self.c1 - self.c0)
+        check(self._L.lpbox_big_get_x_sol(self._h, out), "lpbox_big_get_x_sol")
+        return out

@@ -120,3 +120,32 @@ def run_l2f_seg(solver, score_fn, ws=10, max_iter=30, min_fix=10):
         if n <= min_fix:                                                              # SEG/trainer.py:735-736
             n = 0
     return dict(energy=solver.get_obj(), windows=windows, fixed=fixed)
+
+
+def run_l2f_big(big, score_fn_torch, ws=100, max_iter=10000, tokens=20, min_fix=10, C=0.9):
+    """The loop on ONE large variable-sharded instance (BASELINE config 5; lpbox_hip.big.BigLp, one process per GPU): every rank
+    scores ITS OWN live variables from its device-resident x_iters (no gather); the only extra collective is the sum of the
+    per-rank fix counts, which the "<= 10 fixes => none" rule (LP/trainer.py:533-535) and the shrunken sphere radius need."""
+    import torch
+    vec, num, windows, fixed = None, 0, 0, 0
+    for w in range(int(max_iter / ws)):
+        ret = big.solve_iter_l2f(ws * w, ws * (w + 1), vec, num)
+        windows += 1
+        fixed += num
+        if ret:
+            break
+        X = big.x_iters_torch(ws)                                       # (local live rows, ws) fp64 on the device
+        if hasattr(score_fn_torch, "scores_from_xiters"):
+            off = torch.arange(X.shape[0], device=X.device, dtype=torch.int64) * ws
+            sig = score_fn_torch.scores_from_xiters(X.reshape(-1), off, ws // tokens).reshape(-1)
+        elif X.shape[0]:
+            sig = score_fn_torch(X.view(-1, tokens, ws // tokens).to(torch.float32)).reshape(-1)
+        else:
+            sig = torch.zeros(0, device=X.device)
+        v = torch.where(sig > C, 1.0, torch.where(sig < 1 - C, 0.0, -1.0)).to(torch.float64).cpu().numpy()
+        num = big.sum_over_ranks(int(np.count_nonzero(v != -1)))
+        if num <= min_fix:
+            vec, num = None, 0
+        else:
+            vec = v
+    return dict(objective=-big.cal_Obj(), windows=windows, fixed=fixed, live=big.scalar("n_live"))

@@ -174,6 +174,16 @@ int lpbox_big_set_problem(lpbox_big_t *h, long n_glob, int c0, int n_loc, int l,
                           const double *b, const double *f);
 int lpbox_big_init(lpbox_big_t *h);                                             /* ADMM_lp_iters_init LPcpp:489-763 */
 int lpbox_big_iterate(lpbox_big_t *h, int iter_start, int iter_end, int *ret);  /* ADMM_lp_iters      LPcpp:766-1095 */
+/* ADMM_lp_iters_l2f (LPcpp:1098-1574) on the sharded instance.  vec_local: this rank's slice of the fix vector, one entry per LOCAL
+ * live variable in ascending order (1.0 / 0.0 fix, anything else leave); num_global: number of fixes over ALL ranks (callers sum their
+ * local counts with one tiny all-reduce; it sets the shrunken n of the sphere projection, LPcpp:427).  x_iters of the window stay on
+ * the device per rank: a policy scores its own shard, no gather. */
+int lpbox_big_iterate_l2f(lpbox_big_t *h, int iter_start, int iter_end, const double *vec_local, long num_global, int *ret);
+int lpbox_big_get_n(lpbox_big_t *h);                                            /* live variables of this rank */
+int lpbox_big_get_x_iters(lpbox_big_t *h, int ws, double *out);                 /* (rows x ws) row-major; out == NULL: rows */
+int lpbox_big_get_x_iters_device(lpbox_big_t *h, int ws, void **dev_ptr, int *rows);
+int lpbox_big_get_x_sol(lpbox_big_t *h, double *out_local);                     /* binary: fixed value / rounded x (LPcpp:1648-1666) */
+int lpbox_big_cal_obj(lpbox_big_t *h, double *out);                             /* sum_fix_obj + cur_obj (LPcpp:1630-1642) */
 int lpbox_big_get_x(lpbox_big_t *h, double *out_local);                         /* this rank's slice of x_sol */
 int lpbox_big_get_vec(lpbox_big_t *h, const char *name, double *out, long cap); /* "x","z1","z2","pd" (local), "z4","Ex" (rows) */
 int lpbox_big_get_scalar(lpbox_big_t *h, const char *name, double *out);        /* "cur_obj","iter","stop","outer_total","pcg_total",... */
