@@ -166,8 +166,9 @@ class FusedEarlyFixPolicy:
     reference's (rows, tokens, 5) float input for convenience.  Agreement with the fp32 reference network: ~1e-3 on the
     sigmoid (fp16 operands, fp32 accumulation), tested at 5e-3."""
 
-    def __init__(self, state_dict, tokens=20, device="cuda"):
+    def __init__(self, state_dict, tokens=20, device="cuda", chunk_rows=262144):
         from . import _lib
+        self.chunk_rows = int(chunk_rows)      # bounds the flattened activation buffer (rows x tokens*128 fp16 = 1.3 GB at 20 tokens)
         self._L = _lib.load()
         self._check = _lib.check
         ref = EarlyFixPolicy(state_dict, tokens=tokens, device="cpu")          # validates names/shapes, folds BN and the position code
@@ -215,12 +216,15 @@ class FusedEarlyFixPolicy:
 
     @torch.no_grad()
     def logits_from_xiters(self, flat, row_off, tok_stride=None):
-        z = self.encode(flat, row_off, CODE_DIM if tok_stride is None else tok_stride)
-        for k, (w, b) in enumerate(self.head):
-            z = torch.addmm(b, z, w)
-            if k < 3:
-                z = torch.relu(z)
-        return z.reshape(-1).to(torch.float32)
+        out = torch.empty(row_off.numel(), device=self.device, dtype=torch.float32)
+        for r0 in range(0, row_off.numel(), self.chunk_rows):
+            z = self.encode(flat, row_off[r0:r0 + self.chunk_rows], CODE_DIM if tok_stride is None else tok_stride)
+            for k, (w, b) in enumerate(self.head):
+                z = torch.addmm(b, z, w)
+                if k < 3:
+                    z = torch.relu(z)
+            out[r0:r0 + self.chunk_rows] = z.reshape(-1)
+        return out
 
     def scores_from_xiters(self, flat, row_off, tok_stride=None):
         return torch.sigmoid(self.logits_from_xiters(flat, row_off, tok_stride))
