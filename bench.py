@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=256, help="instances per GPU (default: the 256 of BASELINE configs[1])")
-    ap.add_argument("--cpu-sample", type=int, default=8, help="instances solved by the CPU oracle for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=32, help="instances solved by the CPU oracle for cpu_baseline (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
