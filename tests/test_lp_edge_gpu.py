@@ -1,0 +1,63 @@
+"""Edge cases of the batched LP path: ragged batches (instances of different n, l, nnz in one launch), an instance with an empty
+column and an empty row, a single-variable-per-row instance; each against the oracle in the kernels' order, bit-exact."""
+import numpy as np
+import pytest
+
+from helpers import bits_equal, lp_instances, oracle_for
+from lpbox_hip.lp import LpBatch
+
+pytestmark = pytest.mark.gpu
+
+
+def _csc(cols, l):
+    colptr, rowidx = [0], []
+    for c in cols:
+        rowidx += sorted(c)
+        colptr.append(len(rowidx))
+    return dict(n=len(cols), l=l, nnz=len(rowidx), colptr=np.array(colptr, np.int32), rowidx=np.array(rowidx, np.int32))
+
+
+def _check(insts, windows=((0, 40), (40, 400))):
+    b = LpBatch(insts)
+    b.solve_init()
+    os_ = [oracle_for(b, i, I) for i, I in enumerate(insts)]
+    for (a, e) in windows:
+        rets = b.solve_iter(a, e)
+        for i, o in enumerate(os_):
+            ro = o.solve_iter(a, e)
+            assert rets[i] == ro, (i, a, e)
+            for name in ("x", "z1", "z2", "z4"):
+                assert bits_equal(b.debug_vec(name, i), o.vec(name)), (i, name, a, e)
+            assert b.counters(i) == (o.total_outer_iters, o.total_pcg_iters), i
+    return b, os_
+
+
+def test_ragged_batch_of_three_sizes():
+    small = lp_instances("lp_20_60_seed0.npz")[:3]
+    mid = lp_instances("lp_100_500_seed0.npz")[:2]
+    _check([small[0], mid[0], small[1], mid[1], small[2]])
+
+
+def test_empty_column_and_empty_row():
+    rs = np.random.RandomState(7)
+    cols = [list(rs.choice(12, size=rs.randint(1, 4), replace=False)) for _ in range(30)]
+    cols[5] = []                                     # a bid on nothing: column without entries (pd = rho1 + rho2 only)
+    cols = [[r for r in c if r != 9] for c in cols]   # item 9 is in no bid: empty row (y3 = f, contributes nothing)
+    I = _csc(cols, 12)
+    I["b"] = -rs.uniform(1, 100, size=I["n"])
+    _check([I])
+
+
+def test_identity_like_constraints():
+    n = 40
+    I = _csc([[j] for j in range(n)], n + 1)         # every variable alone in its row (n == l is refused: reference quirk Q5, LPcpp:103-107)
+    I["b"] = -np.linspace(1, 50, n)
+    _check([I])
+
+
+def test_square_instance_is_refused_loudly():
+    from lpbox_hip.lp import LpboxError
+    I = _csc([[j] for j in range(8)], 8)
+    I["b"] = -np.ones(8)
+    with pytest.raises(LpboxError, match="n == l"):
+        LpBatch([I])
