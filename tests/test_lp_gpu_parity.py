@@ -132,3 +132,38 @@ def test_batch_matches_single_instances():
         assert B.counters(i) == (o.total_outer_iters, o.total_pcg_iters)
         assert np.array_equal(B.get_x_sol(i), o.get_x_sol().ravel())
         assert B.cal_obj(i) == o.cal_Obj()
+
+
+def test_full_256_batch_size_independent_properties():
+    """BASELINE config 2 at full size (256 instances), where the oracle would need minutes: properties that need no oracle.
+    (1) determinism: two solves are bit-identical; (2) permutation invariance: an instance's result does not depend on its slot or
+    its neighbours (one workgroup each); (3) the reported objective is b . x_sol recomputed on the host, x_sol is binary and
+    satisfies E x <= 1 wherever check_infeasible says so; (4) a slice of the batch equals the oracle (ties the rest to parity)."""
+    from lpbox_hip.lp import LpBatch
+    insts = lp_instances("lp_100_500_seed0.npz")
+    assert len(insts) == 256
+    B = LpBatch(insts)
+
+    def solve(batch):
+        batch.solve_init()
+        batch.solve_iter(0, 20000)
+        return [(batch.get_x_sol(i).copy(), batch.cal_obj(i), batch.counters(i), batch.debug_vec("x", i)) for i in range(batch.B)]
+    r1 = solve(B)
+    r2 = solve(B)
+    perm = np.random.RandomState(0).permutation(256)
+    rp = solve(LpBatch([insts[k] for k in perm]))
+    for i in range(256):
+        assert r1[i][1] == r2[i][1] and r1[i][2] == r2[i][2] and bits_equal(r1[i][3], r2[i][3]), i
+    for slot, k in enumerate(perm):
+        assert rp[slot][1] == r1[k][1] and rp[slot][2] == r1[k][2] and bits_equal(rp[slot][3], r1[k][3]), (slot, k)
+    for i, I in enumerate(insts):
+        x = r1[i][0].ravel()
+        assert set(np.unique(x)) <= {0.0, 1.0}
+        assert abs(float(I["b"] @ x) - r1[i][1]) <= 1e-9 * max(1.0, abs(r1[i][1]))
+        rows = np.zeros(I["l"])
+        np.add.at(rows, I["rowidx"], np.repeat(x, np.diff(I["colptr"])))
+        assert int((rows > 1.0).sum()) == B.check_infeasible_l2f(i)
+    for i in (0, 97, 255):
+        o = oracle_for(B, i, insts[i])
+        o.solve_iter(0, 20000)
+        assert r1[i][2] == (o.total_outer_iters, o.total_pcg_iters) and bits_equal(r1[i][3], o.vec("x"))
