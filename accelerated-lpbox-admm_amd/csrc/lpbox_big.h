@@ -41,6 +41,7 @@ struct BigDev {
     const int *rptr, *rcol, *cptr, *crow;
     double *x, *y1, *y2, *z1, *z2, *b, *pd, *dinv, *rhs, *r, *z, *tmp, *p0, *p1, *gsrc;   // local n-vectors
     double *y3, *z4, *f, *fy, *Ex, *q;    // replicated l-vectors (q doubles as the all-reduce buffer of E*v)
+    double2 *zp;                          // (z, p) of the last PCG update packed per variable: ONE 16-byte gather per entry of E*p
     double *xt;                           // PCG iterate (committed to x for the live variables after the PCG)
     uint8_t *live;                        // 1 live, 0 fixed (x holds the fixed value)
     const uint8_t *newfix;                // this call's fix request: 0 none, 1 -> 0.0, 2 -> 1.0

@@ -41,6 +41,7 @@ struct lpbox_big {
     Buf<int> d_rptr, d_rcol, d_cptr, d_crow;
     Buf<double> x, y1, y2, z1, z2, db, pd, dinv, rhs, r, z, tmp, p0, p1, gsrc, y3, z4, df, fy, Ex, q, part, red, xt, xhist, xi_out;
     Buf<uint8_t> live, newfix;
+    Buf<double2> zp;
     Buf<int> d_live_idx;
     std::vector<int> left_idx, xi_left;   // local indices of the live variables (now / as of the last l2f window)
     long n_live_glob = 0;                 // live variables over all ranks
@@ -56,7 +57,7 @@ struct lpbox_big {
         d.rptr = d_rptr.p; d.rcol = d_rcol.p; d.cptr = d_cptr.p; d.crow = d_crow.p;
         d.x = x.p; d.y1 = y1.p; d.y2 = y2.p; d.z1 = z1.p; d.z2 = z2.p; d.b = db.p; d.pd = pd.p; d.dinv = dinv.p; d.rhs = rhs.p;
         d.r = r.p; d.z = z.p; d.tmp = tmp.p; d.p0 = p0.p; d.p1 = p1.p; d.gsrc = gsrc.p;
-        d.xt = xt.p; d.live = live.p; d.newfix = newfix.p; d.xhist = xhist.p; d.ws_cap = ws_cap;
+        d.zp = zp.p; d.xt = xt.p; d.live = live.p; d.newfix = newfix.p; d.xhist = xhist.p; d.ws_cap = ws_cap;
         d.y3 = y3.p; d.z4 = z4.p; d.f = df.p; d.fy = fy.p; d.Ex = Ex.p; d.q = ext_q ? ext_q : q.p; d.part = part.p; d.red = ext_red ? ext_red : red.p; d.st = st.p;
         return d;
     }
@@ -142,7 +143,7 @@ void lpbox_big_destroy(lpbox_big_t *h) {
     for (Buf<double> *bp : {&h->x, &h->y1, &h->y2, &h->z1, &h->z2, &h->db, &h->pd, &h->dinv, &h->rhs, &h->r, &h->z, &h->tmp, &h->p0, &h->p1,
                             &h->gsrc, &h->y3, &h->z4, &h->df, &h->fy, &h->Ex, &h->q, &h->part, &h->red, &h->xt, &h->xhist, &h->xi_out})
         bp->release();
-    h->st.release(); h->live.release(); h->newfix.release(); h->d_live_idx.release();
+    h->st.release(); h->live.release(); h->newfix.release(); h->d_live_idx.release(); h->zp.release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -211,7 +212,7 @@ int lpbox_big_init(lpbox_big_t *h) {
         HIPCHK(h->d_rptr.alloc((size_t)l + 1)); HIPCHK(h->d_rcol.alloc(h->nnz)); HIPCHK(h->d_cptr.alloc((size_t)n + 1)); HIPCHK(h->d_crow.alloc(h->nnz));
         for (Buf<double> *bp : {&h->x, &h->y1, &h->y2, &h->z1, &h->z2, &h->db, &h->pd, &h->dinv, &h->rhs, &h->r, &h->z, &h->tmp, &h->p0, &h->p1, &h->gsrc, &h->xt})
             HIPCHK(bp->alloc(n));
-        HIPCHK(h->live.alloc(n)); HIPCHK(h->newfix.alloc(n)); HIPCHK(h->d_live_idx.alloc(n));
+        HIPCHK(h->live.alloc(n)); HIPCHK(h->newfix.alloc(n)); HIPCHK(h->d_live_idx.alloc(n)); HIPCHK(h->zp.alloc(n));
         HIPCHK(hipMemset(h->newfix.p, 0, (size_t)n));
         for (Buf<double> *bp : {&h->y3, &h->z4, &h->df, &h->fy, &h->Ex, &h->q}) HIPCHK(bp->alloc(l));
         HIPCHK(h->part.alloc((size_t)BIG_NPART * h->G)); HIPCHK(h->red.alloc(BIG_NPART)); HIPCHK(h->st.alloc(2));

@@ -217,7 +217,14 @@ __global__ void __launch_bounds__(T) big_k_rhs_cols(BigDev d, int in, int out) {
         if (j >= d.n_loc) continue;
         double tA = 0.0, tB = 0.0;
         const int k1 = d.cptr[j + 1];
-        for (int k = d.cptr[j]; k < k1; k++) { const int i = d.crow[k]; tA += r4Et * d.fy[i]; tB += d.z4[i]; }
+        int k = d.cptr[j];
+        for (; k + 4 <= k1; k += 4) {                      // 4 gathers in flight, additions in column order
+            const int i0 = d.crow[k], i1 = d.crow[k + 1], i2 = d.crow[k + 2], i3 = d.crow[k + 3];
+            const double a0 = d.fy[i0], a1 = d.fy[i1], a2 = d.fy[i2], a3 = d.fy[i3];
+            const double b0 = d.z4[i0], b1 = d.z4[i1], b2 = d.z4[i2], b3 = d.z4[i3];
+            tA += r4Et * a0; tB += b0; tA += r4Et * a1; tB += b1; tA += r4Et * a2; tB += b2; tA += r4Et * a3; tB += b3;
+        }
+        for (; k < k1; k++) { const int i = d.crow[k]; tA += r4Et * d.fy[i]; tB += d.z4[i]; }
         double r_ = d.rhs[j];
         r_ += tA;
         r_ -= tB;
@@ -263,15 +270,40 @@ __global__ void __launch_bounds__(T) big_k_rows(BigDev d, int in, int out, int m
         if (done) return;
         pold = ((k - 1) & 1) ? d.p1 : d.p0;
     } else forward_state(d, in, out);
-    const double *gs = d.gsrc, *zz = d.z, *p0 = d.p0;
+    const double *gs = d.gsrc, *p0 = d.p0;
+    (void)pold;
     for (int s = 0; s < d.EPTl; s++) {
         const int i = blockIdx.x * (T * d.EPTl) + s * T + threadIdx.x;
         if (i >= d.l) continue;
         double acc = 0.0;
         const int k1 = d.rptr[i + 1];
-        if (mode == 0) for (int k = d.rptr[i]; k < k1; k++) acc += gs[d.rcol[k]];
-        else if (first) for (int k = d.rptr[i]; k < k1; k++) acc += p0[d.rcol[k]];
-        else for (int k = d.rptr[i]; k < k1; k++) { const int c = d.rcol[k]; acc += zz[c] + beta * pold[c]; }
+        int k = d.rptr[i];
+        // the row is summed in ascending column order by this one lane; the gathers of 8 entries are issued together so that
+        // their latencies overlap (the additions stay sequential: same rounding as the one-at-a-time loop)
+        if (mode == 0 || first) {
+            const double *src = mode == 0 ? gs : p0;
+            for (; k + 8 <= k1; k += 8) {
+                int c[8]; double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) c[u] = d.rcol[k + u];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = src[c[u]];
+#pragma unroll
+                for (int u = 0; u < 8; u++) acc += v[u];
+            }
+            for (; k < k1; k++) acc += src[d.rcol[k]];
+        } else {
+            for (; k + 8 <= k1; k += 8) {
+                int c[8]; double2 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) c[u] = d.rcol[k + u];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = d.zp[c[u]];
+#pragma unroll
+                for (int u = 0; u < 8; u++) acc += v[u].x + beta * v[u].y;
+            }
+            for (; k < k1; k++) { const double2 v = d.zp[d.rcol[k]]; acc += v.x + beta * v.y; }
+        }
         d.q[i] = acc;
     }
 }
@@ -289,7 +321,12 @@ __global__ void __launch_bounds__(T) big_k_resid(BigDev d, int in, int out) {   
         if (j < d.n_loc) {
             double t = 0.0;
             const int k1 = d.cptr[j + 1];
-            for (int k = d.cptr[j]; k < k1; k++) t += r4Et * d.q[d.crow[k]];
+            int k = d.cptr[j];
+            for (; k + 4 <= k1; k += 4) {
+                const double v0 = d.q[d.crow[k]], v1 = d.q[d.crow[k + 1]], v2 = d.q[d.crow[k + 2]], v3 = d.q[d.crow[k + 3]];
+                t += r4Et * v0; t += r4Et * v1; t += r4Et * v2; t += r4Et * v3;
+            }
+            for (; k < k1; k++) t += r4Et * d.q[d.crow[k]];
             const double y1 = d.y1[j];
             double Mx = 0.0;
             Mx += dI * (1.0 * y1);
@@ -333,7 +370,12 @@ __global__ void __launch_bounds__(T) big_k_pcg_cols(BigDev d, int in, int out) {
             else { pj = d.z[j] + beta * pold[j]; pnew[j] = pj; }                  // p = z + beta p (:319)
             double t = 0.0;
             const int k1 = d.cptr[j + 1];
-            for (int kk = d.cptr[j]; kk < k1; kk++) t += r4Et * d.q[d.crow[kk]];
+            int kk = d.cptr[j];
+            for (; kk + 4 <= k1; kk += 4) {
+                const double v0 = d.q[d.crow[kk]], v1 = d.q[d.crow[kk + 1]], v2 = d.q[d.crow[kk + 2]], v3 = d.q[d.crow[kk + 3]];
+                t += r4Et * v0; t += r4Et * v1; t += r4Et * v2; t += r4Et * v3;
+            }
+            for (; kk < k1; kk++) t += r4Et * d.q[d.crow[kk]];
             double Mp = 0.0;
             Mp += dI * (1.0 * pj);
             Mp += t;
@@ -369,6 +411,7 @@ __global__ void __launch_bounds__(T) big_k_pcg_upd(BigDev d, int in, int out) { 
                 const double z = d.dinv[j] * r;
                 const bool lv = d.live[j];
                 d.xt[j] = x; d.r[j] = r; d.z[j] = lv ? z : 0.0;
+                d.zp[j] = make_double2(lv ? z : 0.0, p[j]);          // what rows() gathers for the next search direction z + beta p
                 if (lv) { a = r * r; b2 = r * z; }
             }
             pd2[0] = pd2[0] + a; pd2[1] = pd2[1] + b2;
