@@ -590,8 +590,10 @@ int sego_get_vec(const sego_t *o, const char *name, double *out, int cap) {
     return len;
 }
 double sego_get_scalar(const sego_t *o, const char *name) {
-    if (!strcmp(name, "rho1")) return o->rho1; if (!strcmp(name, "gamma")) return o->gamma_val; if (!strcmp(name, "cur_obj")) return o->cur_obj;
-    if (!strcmp(name, "std_obj")) return o->std_obj; if (!strcmp(name, "cvg1")) return o->cvg1; if (!strcmp(name, "cvg2")) return o->cvg2;
-    if (!strcmp(name, "obj_val")) return o->obj_val; if (!strcmp(name, "best_bin_obj")) return o->best_bin_obj;
+    const struct { const char *n; double v; } tab[] = {
+        {"rho1", o->rho1}, {"gamma", o->gamma_val}, {"cur_obj", o->cur_obj}, {"std_obj", o->std_obj}, {"cvg1", o->cvg1},
+        {"cvg2", o->cvg2}, {"obj_val", o->obj_val}, {"best_bin_obj", o->best_bin_obj},
+    };
+    for (size_t k = 0; k < sizeof(tab) / sizeof(tab[0]); k++) if (!strcmp(name, tab[k].n)) return tab[k].v;
     return NAN;
 }
