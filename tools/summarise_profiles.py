@@ -1,0 +1,46 @@
+"""Turn gpurun_out/prof_* (tools/collect_profiles.sh) into the committed round summaries under profiles/."""
+import csv, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+O = os.path.join(ROOT, "gpurun_out")
+P = os.path.join(ROOT, "profiles")
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+
+
+def stats(src, dst, keep=12):
+    rows = list(csv.reader(open(src)))
+    with open(dst, "w", newline="") as f:
+        csv.writer(f).writerows(rows[:keep + 1])
+
+
+def counter(path, name, kernel_substr):
+    vals = {}
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == name and kernel_substr in r["Kernel_Name"]:
+            vals.setdefault(r["Dispatch_Id"], 0.0)
+            vals[r["Dispatch_Id"]] += float(r["Counter_Value"])
+    v = list(vals.values())
+    return sum(v) / len(v), len(v)
+
+
+stats(os.path.join(O, "prof_bench", "bench_kernel_stats.csv"), os.path.join(P, rnd + "_kernel_stats.csv"))
+stats(os.path.join(O, "prof_policy", "policy_kernel_stats.csv"), os.path.join(P, rnd + "_policy_kernel_stats.csv"))
+stats(os.path.join(O, "prof_big", "big_kernel_stats.csv"), os.path.join(P, rnd + "_big_kernel_stats.csv"))
+stats(os.path.join(O, "prof_seg", "seg_kernel_stats.csv"), os.path.join(P, rnd + "_seg_kernel_stats.csv"))
+fetch_kb, nf = counter(os.path.join(O, "prof_fetch", "fetch_counter_collection.csv"), "FETCH_SIZE", "lp_window_kernel")
+write_kb, nw = counter(os.path.join(O, "prof_write", "write_counter_collection.csv"), "WRITE_SIZE", "lp_window_kernel")
+out = {
+    "command": "rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python3 bench.py --steps 2 --warmup 1 --cpu-sample 0 ; same with --pmc WRITE_SIZE (two separate passes, tools/collect_profiles.sh)",
+    "kernel": "lp_window_kernel<512,1,Caps<12>,Caps<24>>",
+    "launches_sampled": [nf, nw],
+    "FETCH_SIZE_KB_per_launch": fetch_kb,
+    "WRITE_SIZE_KB_per_launch": write_kb,
+    "hbm_bytes_per_launch": (2 * fetch_kb + write_kb) * 1024,
+    "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B read requests at 64 B; calibrated there for wide coalesced reads, our 8-byte/2-byte loads are not, so this is an upper estimate). One launch = one full solve of the 256-instance batch: the solve is register/LDS resident, HBM sees the state once in and once out.",
+}
+json.dump(out, open(os.path.join(P, rnd + "_pmc_traffic.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
+for name in ("prof_bench", "prof_policy", "prof_big", "prof_seg"):
+    log = os.path.join(O, name + ".log")
+    for ln in open(log):
+        if ln.startswith("{") or ln.startswith("rows ") or ln.startswith("n="):
+            print(name, ln.strip()[:300])
