@@ -15,34 +15,67 @@ __device__ __forceinline__ double dpp_mov(double v) {
     return __hiloint2double(hi, lo);
 }
 
-// 64-lane all-reduce, association = balanced binary tree over the lane index (pairs, quads, ..., halves).
-// Steps 3/4 use row_half_mirror / row_mirror: after the quad steps every lane of a quad (8-group) holds the same
-// partial, so the mirrored partner carries exactly the xor-4 (xor-8) partner's value.
-__device__ __forceinline__ double wave_allreduce_sum(double v) {
-#ifdef LPBOX_REDUCE_SHFL
-    for (int off = 1; off < 64; off <<= 1) v = v + __shfl_xor(v, off, 64);
-    return v;
-#else
+// The fixed reduction tree of a 64-lane wavefront, per value: halves first (lane l + lane l^32), then the two row pairs (l^16),
+// then inside a row of 16 lanes pairs, quads, 8, 16.  Putting the two wide steps FIRST lets several values share them: a
+// v_permlane32_swap / v_permlane16_swap of two DIFFERENT values is a reduce-scatter step (one half / row keeps value A, the other
+// value B), so NV values cost one narrow butterfly instead of NV (wave_reduce_scatter below).  Floating-point addition is
+// commutative, so "own + partner" and "partner + own" are the same bits and every lane of a group holds the identical partial.
+struct HalfSwap {           // r0 = [a.lanes 0-31 , b.lanes 0-31], r1 = [a.lanes 32-63, b.lanes 32-63]
+    static __device__ __forceinline__ void run(double a, double b, double &r0, double &r1) {
+        auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+        auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+        r0 = __hiloint2double(hi[0], lo[0]); r1 = __hiloint2double(hi[1], lo[1]);
+    }
+};
+struct RowSwap {            // r0 = rows [a0, b0, a2, b2], r1 = rows [a1, b1, a3, b3] (rows of 16 lanes)
+    static __device__ __forceinline__ void run(double a, double b, double &r0, double &r1) {
+        auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
+        auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
+        r0 = __hiloint2double(hi[0], lo[0]); r1 = __hiloint2double(hi[1], lo[1]);
+    }
+};
+// one wide step for two values: the lower half / even rows end up with a's pair sums, the upper half / odd rows with b's
+template <typename SWAP>
+__device__ __forceinline__ double pair_step(double a, double b) { double r0, r1; SWAP::run(a, b, r0, r1); return r0 + r1; }
+
+__device__ __forceinline__ double row_allreduce(double v) {      // inside each row of 16 lanes: pairs, quads, 8, 16
     v = v + dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
     v = v + dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
-    v = v + dpp_mov<0x141>(v);   // row_half_mirror
-    v = v + dpp_mov<0x140>(v);   // row_mirror
-    {
-        int lo = __double2loint(v), hi = __double2hiint(v);
-        auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-        auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-        // a[0]/b[0]: rows {0,0,2,2}; a[1]/b[1]: rows {1,1,3,3} of the input -> even-row + odd-row partial
-        v = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
-    }
-    {
-        int lo = __double2loint(v), hi = __double2hiint(v);
-        auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-        auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-        v = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);   // lower half + upper half
-    }
+    v = v + dpp_mov<0x141>(v);   // row_half_mirror: after the quad steps the mirrored partner holds the xor-4 partner's value
+    v = v + dpp_mov<0x140>(v);   // row_mirror: likewise xor-8
     return v;
+}
+
+// 64-lane all-reduce of one value (every lane receives the sum).
+__device__ __forceinline__ double wave_allreduce_sum(double v) {
+#ifdef LPBOX_REDUCE_SHFL
+    v = v + __shfl_xor(v, 32, 64); v = v + __shfl_xor(v, 16, 64);
+    for (int off = 1; off < 16; off <<= 1) v = v + __shfl_xor(v, off, 64);
+    return v;
+#else
+    v = pair_step<HalfSwap>(v, v);
+    v = pair_step<RowSwap>(v, v);
+    return row_allreduce(v);
 #endif
 }
+
+// NV <= 4 values through ONE narrow butterfly: on return the total of value k sits in every lane of row ROW_OF[k]
+// (rows of 16 lanes: value 0 -> row 0, 1 -> row 2, 2 -> row 1, 3 -> row 3); the result is returned in `out`, to be read
+// only in those rows.  Same per-value tree as wave_allreduce_sum.
+template <int NV>
+__device__ __forceinline__ double wave_reduce_scatter(const double *v) {
+    static_assert(NV >= 2 && NV <= 4, "2..4 values");
+    const double x = pair_step<HalfSwap>(v[0], v[1]);                                   // lower half: value 0, upper half: value 1
+    double s;
+    if constexpr (NV == 2) s = pair_step<RowSwap>(x, x);
+    else {
+        const double y = NV == 4 ? pair_step<HalfSwap>(v[2], v[3]) : pair_step<HalfSwap>(v[2], v[2]);
+        s = pair_step<RowSwap>(x, y);                                                   // rows: [v0, v2, v1, v3 (or v2 again)]
+    }
+    return row_allreduce(s);
+}
+// lane that owns value k after wave_reduce_scatter<NV>
+__device__ __forceinline__ constexpr int scatter_lane(int nv, int k) { return nv == 2 ? 32 * k : (k == 0 ? 0 : k == 1 ? 32 : k == 2 ? 16 : 48); }
 
 __device__ __forceinline__ int wave_max_int(int v) {
     for (int off = 1; off < 64; off <<= 1) { int o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
@@ -60,14 +93,27 @@ template <int T, int NV>
 __device__ __forceinline__ void block_sum(double (&v)[NV], double *red, int &parity) {
     constexpr int W = T / 64;
     static_assert(W == 1 || W == 2 || W == 4 || W == 8 || W == 16, "waves per workgroup");
+    if constexpr (W == 1) {              // one wavefront per instance: no LDS round trip, no barrier
 #pragma unroll
-    for (int k = 0; k < NV; k++) v[k] = wave_allreduce_sum(v[k]);
-    if constexpr (W == 1) return;        // one wavefront per instance: no LDS round trip, no barrier
+        for (int k = 0; k < NV; k++) v[k] = wave_allreduce_sum(v[k]);
+        return;
+    }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     double *buf = red + parity * (RED_MAXV * RED_MAXW);
-    if (lane == 0) {
+    if constexpr (NV == 1) {
+        const double t0 = wave_allreduce_sum(v[0]);
+        if (lane == 0) buf[w] = t0;
+    } else {
+        // values 0..3 share one butterfly (reduce-scatter); a fifth goes alone
+        constexpr int NS4 = NV > 4 ? 4 : NV;
+        const double sc = wave_reduce_scatter<NS4>(v);
 #pragma unroll
-        for (int k = 0; k < NV; k++) buf[k * RED_MAXW + w] = v[k];
+        for (int k = 0; k < NS4; k++) if (lane == scatter_lane(NS4, k)) buf[k * RED_MAXW + w] = sc;
+        if constexpr (NV > 4) {
+            static_assert(NV <= 5, "at most five values");
+            const double t4 = wave_allreduce_sum(v[4]);
+            if (lane == 0) buf[4 * RED_MAXW + w] = t4;
+        }
     }
     __syncthreads();
     double t[NV];

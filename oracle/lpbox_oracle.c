@@ -305,7 +305,8 @@ static double redux_sum_eigen(const double *a, int size) {
 /* The HIP kernels' fixed reduction tree (accelerated-lpbox-admm_amd/csrc/lpbox_lp_kernels.hip, block_sum):
  * value of ORIGINAL variable position pos is owned by thread pos % T, slot pos / T; a thread adds its slots in
  * ascending order starting from +0.0 (fixed / out-of-range positions contribute +0.0); a 64-lane wavefront
- * combines by an xor-butterfly (pairs, quads, ... halves); the W = T/64 wave partials by the same kind of tree. */
+ * combines lane l with l^32, then l^16, then pairs, quads, 8, 16 inside a row of 16 lanes (lpbox_dev_common.h); the W = T/64 wave
+ * partials by a balanced tree over the wave index. */
 static double redux_sum_gpu_full(const double *full, int len, int T) {
     double local[1024];
     for (int t = 0; t < T; t++) local[t] = 0.0;
@@ -314,8 +315,10 @@ static double redux_sum_gpu_full(const double *full, int len, int T) {
     double part[16];
     for (int w = 0; w < W; w++) {
         double *a = local + 64 * w;
-        for (int stride = 1; stride < 64; stride <<= 1)
-            for (int i = 0; i < 64; i += 2 * stride) a[i] = a[i] + a[i + stride];
+        for (int i = 0; i < 32; i++) a[i] = a[i] + a[i + 32];              /* halves first (v_permlane32_swap) */
+        for (int i = 0; i < 16; i++) a[i] = a[i] + a[i + 16];              /* then the row pairs (v_permlane16_swap) */
+        for (int stride = 1; stride < 16; stride <<= 1)                    /* then pairs, quads, 8, 16 inside a row of 16 lanes (DPP) */
+            for (int i = 0; i < 16; i += 2 * stride) a[i] = a[i] + a[i + stride];
         part[w] = a[0];
     }
     for (int stride = 1; stride < W; stride <<= 1)          /* wave partials: a second balanced tree (block_sum) */

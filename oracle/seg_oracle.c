@@ -85,7 +85,9 @@ static double block_tree(const double *full, int len, int T) {
     double part[16];
     for (int w = 0; w < W; w++) {
         double *a = local + 64 * w;
-        for (int s = 1; s < 64; s <<= 1) for (int i = 0; i < 64; i += 2 * s) a[i] = a[i] + a[i + s];
+        for (int i = 0; i < 32; i++) a[i] = a[i] + a[i + 32];              /* halves first, then row pairs, then inside a row of 16 lanes */
+        for (int i = 0; i < 16; i++) a[i] = a[i] + a[i + 16];
+        for (int s = 1; s < 16; s <<= 1) for (int i = 0; i < 16; i += 2 * s) a[i] = a[i] + a[i + s];
         part[w] = a[0];
     }
     for (int s = 1; s < W; s <<= 1) for (int i = 0; i < W; i += 2 * s) part[i] = part[i] + part[i + s];
