@@ -82,3 +82,38 @@ def test_fused_encoder_matches_reference_gpu(tag, tokens):
     perm = torch.randperm(1003, generator=torch.Generator().manual_seed(4)).cuda()
     got = fused.scores_from_xiters(flat, perm * (tokens * 5))
     assert (got - ref(xr)[perm]).abs().max().item() < 2e-4
+
+
+@pytest.mark.parametrize("tag,tokens", [("lp", 20), ("seg", 5)])
+def test_trainable_module_is_the_same_network(tag, tokens):
+    """lpbox_hip.train.TrainablePolicy: same state_dict keys/shapes as the reference module, same eval-mode output as the
+    reference's golden vectors (2e-5 on the sigmoid), and its weights drop into the inference class."""
+    from lpbox_hip.train import TrainablePolicy
+    net = TrainablePolicy(tokens)
+    want = P.reference_state_shapes(tokens)
+    assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == {k: tuple(v) for k, v in want.items()}
+    net.load_state_dict(deterministic_state(want))
+    net.eval()
+    x = torch.from_numpy(FIX[tag + "_x"])
+    with torch.no_grad():
+        logit, sig = net(x)
+    assert np.abs(sig.numpy().ravel() - FIX[tag + "_sigmoid"]).max() < 2e-5
+    inf = P.EarlyFixPolicy(net.state_dict(), tokens=tokens, device="cpu")
+    assert np.abs(inf(x).numpy() - sig.numpy().ravel()).max() < 2e-5
+
+
+def test_training_step_reduces_the_loss_cpu():
+    from lpbox_hip.train import TrainablePolicy, train
+    torch.manual_seed(0)
+    net = TrainablePolicy(20)
+    g = torch.Generator().manual_seed(1)
+    # two synthetic "instances": variables that end at 1 drift upwards, the others downwards
+    hist, labels = [], []
+    for _ in range(2):
+        y = (torch.rand(40, 1, generator=g) > 0.6).float()
+        t = torch.linspace(0, 1, 1000).view(1, -1)
+        h = 0.5 + (y - 0.5) * t + 0.05 * torch.randn(40, 1000, generator=g)
+        hist.append(h.double())
+        labels.append(y)
+    losses = train(net, hist, labels, epochs=6, lr=1e-3)
+    assert losses[-1] < 0.7 * losses[0]
