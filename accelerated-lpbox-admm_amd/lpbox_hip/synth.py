@@ -50,3 +50,20 @@ def make_auction_like(n, seed=0, item_frac=0.3, add_prob=0.78, max_items=14):
     cnt = np.diff(colptr)
     price += np.power(cnt, 1.2)
     return dict(n=int(n), l=int(l), colptr=colptr.astype(np.int32), rowidx=item.astype(np.int32), b=-price)
+
+
+def write_instance_files(inst, path_C, path_b):
+    """An instance dict (n, l, colptr, rowidx, b) in the reference's on-disk format (generate_instances.py:339-359, read back by
+    readSparseMat / readDenseVec, LPcpp:2407-2444): `<row>,<col>,1` per entry, 1-based, ROW-major with ascending columns; one price
+    per line.  `b` holds the negated prices (LPcpp:2520), so the file gets -b, printed with repr() like the generator's f-string."""
+    n, l = int(inst["n"]), int(inst["l"])
+    colptr, rowidx = np.asarray(inst["colptr"]), np.asarray(inst["rowidx"])
+    cols = np.repeat(np.arange(n), np.diff(colptr))
+    order = np.lexsort((cols, rowidx))                    # by row, then by column
+    with open(path_C, "w") as f:
+        for r, c in zip(rowidx[order], cols[order]):
+            f.write("%d,%d,1\n" % (r + 1, c + 1))
+    with open(path_b, "w") as f:
+        for v in np.asarray(inst["b"], np.float64):
+            f.write("%r\n" % float(-v))
+    return l

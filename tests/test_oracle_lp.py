@@ -200,3 +200,19 @@ def test_summation_order_changes_trajectories_not_solution_quality():
     objs = np.array(objs)
     assert 0 < np.mean(bits) < 0.15                                   # different end points ...
     assert abs(objs[:, 1].mean() - objs[:, 0].mean()) < 0.04 * objs[:, 0].mean()    # ... of the same quality
+
+
+def test_instance_file_writer_roundtrip(tmp_path):
+    """lpbox_hip.synth.write_instance_files reproduces the reference generator's files byte for byte (the committed fixture) and the
+    oracle's reader (LPcpp:2407-2545) reads them back to the same problem."""
+    import filecmp
+    from lpbox_hip.synth import write_instance_files
+    I = lp_instances("lp_100_500_seed0.npz")[0]
+    pc, pb = str(tmp_path / "instance_1_C.txt"), str(tmp_path / "instance_1_b.txt")
+    write_instance_files(I, pc, pb)
+    assert filecmp.cmp(pc, os.path.join(GOLDEN, "instance/100_500/instance_1_C.txt"), shallow=False)
+    assert filecmp.cmp(pb, os.path.join(GOLDEN, "instance/100_500/instance_1_b.txt"), shallow=False)
+    o = O.LpOracle(0)
+    o.read_files(pc, pb, 100)
+    o.solve_init()
+    assert o.get_n() == I["n"] and np.array_equal(o.vec("b"), I["b"])
