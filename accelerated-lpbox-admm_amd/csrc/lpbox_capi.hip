@@ -801,7 +801,8 @@ int lpbox_get_x_iters(lpbox_t *h, int idx, int ws, double *out) {
 }
 
 int lpbox_get_x_iters_device(lpbox_t *h, int ws, void **dev_ptr, long *stride_doubles) {
-    if (!valid_handle(h) || h->seg) return fail(LPBOX_E_BADHANDLE, "bad handle (LP flavour only)");
+    if (valid_handle(h) && h->seg) return segc_get_x_iters_device(h->seg, ws, dev_ptr, stride_doubles);
+    if (!valid_handle(h)) return fail(LPBOX_E_BADHANDLE, "bad handle");
     if (!h->xi_valid) return fail(LPBOX_E_STATE, "solve_iter_l2f has not been called");
     if (ws <= 0 || ws > h->ws_cap) return fail(LPBOX_E_BADARG, "ws = %d outside (0,%d] (the last window)", ws, h->ws_cap);
     int rc = use_device(h);

@@ -18,6 +18,7 @@ int segc_get_n(SegSolver *s);
 int segc_get_org_n(SegSolver *s);
 int segc_get_iter(SegSolver *s);
 int segc_get_x_iters(SegSolver *s, int ws, double *out);
+int segc_get_x_iters_device(SegSolver *s, int ws, void **dev_ptr, long *stride);
 int segc_set_record(SegSolver *s, int on);
 int segc_get_x_history(SegSolver *s, int first, int count, double *out);
 int segc_get_x_sol(SegSolver *s, double *out);

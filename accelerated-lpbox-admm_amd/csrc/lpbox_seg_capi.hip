@@ -443,6 +443,21 @@ int segc_get_x_iters(SegSolver *s, int ws, double *out) {                     //
     return rows;
 }
 
+// the same (rows x ws) row-major window left on the device (stride = rows * ws doubles: one problem per handle)
+int segc_get_x_iters_device(SegSolver *s, int ws, void **dev_ptr, long *stride) {
+    if (!s->xi_valid) return lpbox_fail(LPBOX_E_STATE, "solve_iter_l2f has not been called");
+    if (ws <= 0 || ws > SEG_XITERS_COLS) return lpbox_fail(LPBOX_E_BADARG, "ws = %d outside (0,%d]", ws, SEG_XITERS_COLS);
+    int rc = use_device(s);
+    if (rc) return rc;
+    const int rows = s->xi_rows;
+    if (s->xi_out.count < (size_t)std::max(rows, 1) * ws) HIPCHK(s->xi_out.alloc((size_t)s->n * SEG_XITERS_COLS));
+    HIPCHK(seg_launch_pack_xiters(s->dev(), s->d_left.p, rows, ws, s->xi_out.p, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    if (dev_ptr) *dev_ptr = s->xi_out.p;
+    if (stride) *stride = (long)rows * ws;
+    return LPBOX_OK;
+}
+
 static int fetch_solution(SegSolver *s, std::vector<double> &sol) {            // get_x_sol SEGcpp:895-914
     std::vector<double> x(s->n); std::vector<uint8_t> live(s->n), fv(s->n);
     HIPCHK(hipMemcpy(x.data(), s->x.p, sizeof(double) * (size_t)s->n, hipMemcpyDeviceToHost));

@@ -122,6 +122,29 @@ def run_l2f_seg(solver, score_fn, ws=10, max_iter=30, min_fix=10):
     return dict(energy=solver.get_obj(), windows=windows, fixed=fixed)
 
 
+def run_l2f_seg_device(solver, policy, ws=10, max_iter=30, min_fix=10, C=0.9):
+    """run_l2f_seg with the iterates read on the device: `policy` is a lpbox_hip.policy.FusedEarlyFixPolicy(tokens=5); token j of a
+    variable = iterates j .. j+4 of the window (SEG/trainer.py:721-725), i.e. token stride 1 over the packed (n_live x ws) buffer."""
+    import torch
+    n = 0
+    vec = np.zeros(solver.get_n(), dtype=np.double)
+    windows = fixed = 0
+    for i in range(int(max_iter / ws)):
+        ret = solver.solve_iter_l2f(ws * i, ws * (i + 1), vec, n)
+        windows += 1
+        fixed += n
+        if ret:
+            break
+        X = solver.x_iters_torch(ws)
+        off = torch.arange(X.shape[0], device=X.device, dtype=torch.int64) * ws
+        sig = policy.scores_from_xiters(X.reshape(-1), off, 1)
+        vec = torch.where(sig > C, 1.0, torch.where(sig < 1 - C, 0.0, -1.0)).to(torch.float64).cpu().numpy()
+        n = int(np.count_nonzero(vec != -1))
+        if n <= min_fix:
+            n = 0
+    return dict(energy=solver.get_obj(), windows=windows, fixed=fixed)
+
+
 def run_l2f_big(big, score_fn_torch, ws=100, max_iter=10000, tokens=20, min_fix=10, C=0.9):
     """The loop on ONE large variable-sharded instance (BASELINE config 5; lpbox_hip.big.BigLp, one process per GPU): every rank
     scores ITS OWN live variables from its device-resident x_iters (no gather); the only extra collective is the sum of the

@@ -142,6 +142,19 @@ class PyLPboxADMMsolver:
                                         C.cast(nums, C.c_void_p), C.cast(rets, C.c_void_p)), "lpbox_iterate_l2f")
         return rets[0]
 
+    def x_iters_torch(self, ws):
+        """The (n_live x ws) iterate window of the last solve_iter_l2f as a zero-copy torch CUDA tensor."""
+        import torch
+        ptr, stride = C.c_void_p(), C.c_long()
+        check(self._L.lpbox_get_x_iters_device(self._h, _as_int(ws, "ws"), C.byref(ptr), C.byref(stride)), "lpbox_get_x_iters_device")
+        rows = stride.value // int(ws)
+        if rows == 0:
+            return torch.zeros((0, int(ws)), dtype=torch.float64, device="cuda")
+
+        class _Dev:
+            __cuda_array_interface__ = {"shape": (stride.value,), "typestr": "<f8", "data": (ptr.value, False), "version": 2}
+        return torch.as_tensor(_Dev(), device="cuda").view(rows, int(ws))
+
     # SEG pyx:26-33
     def get_x_iters_2d(self, ws):
         ws = _as_int(ws, "ws")

@@ -45,3 +45,24 @@ def test_validation_loop_matches_oracle():
     ro = l2f.run_l2f_seg(o, _near_binary)
     assert rg == ro and rg["fixed"] > 0
     assert np.array_equal(g.get_x_sol(), o.get_x_sol())
+
+
+def test_device_loop_with_fused_policy_equals_host_loop():
+    """SEG variant of row f1: the fused encoder (5 tokens, sliding windows = token stride 1) reads the packed x_iters on the device;
+    the host loop feeds the same policy the reference-shaped (n, 5, 5) windows.  Same decisions, same energy."""
+    import torch
+    from lpbox_hip.policy import FusedEarlyFixPolicy, random_state
+    pol = FusedEarlyFixPolicy(random_state(5, seed=2), tokens=5)
+    # a policy with random weights scores ~0.5 everywhere: sharpen it so that it actually fixes (same function on both paths)
+    class Sharp:
+        def scores_from_xiters(self, flat, off, stride):
+            return torch.sigmoid(5000.0 * (pol.logits_from_xiters(flat, off, stride) - pol.logits_from_xiters(flat, off, stride).median()))
+        def __call__(self, x):
+            lg = pol.logits(torch.from_numpy(x).cuda())
+            return torch.sigmoid(5000.0 * (lg - lg.median())).cpu().numpy()
+    g1, _ = make_pair(10000)
+    g2, _ = make_pair(10000)
+    r_dev = l2f.run_l2f_seg_device(g1, Sharp())
+    r_host = l2f.run_l2f_seg(g2, Sharp())
+    assert r_dev == r_host and r_dev["fixed"] > 0
+    assert np.array_equal(g1.get_x_sol(), g2.get_x_sol())
