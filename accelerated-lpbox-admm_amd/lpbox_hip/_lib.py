@@ -82,6 +82,14 @@ SYMBOLS = {
     "lpbox_big_get_x": (C.c_int, [C.c_void_p, _dp]),
     "lpbox_big_get_vec": (C.c_int, [C.c_void_p, C.c_char_p, _dp, C.c_long]),
     "lpbox_big_get_scalar": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]),
+    "lpbox_bqp_create": (C.c_void_p, [C.c_int]),
+    "lpbox_bqp_destroy": (None, [C.c_void_p]),
+    "lpbox_bqp_preset": (C.c_int, [C.c_void_p, C.c_int]),
+    "lpbox_bqp_set_params": (C.c_int, [C.c_void_p, _dp]),
+    "lpbox_bqp_set_problem": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 4),
+    "lpbox_bqp_solve": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "lpbox_bqp_get_vec": (C.c_int, [C.c_void_p, C.c_char_p, _dp, C.c_long]),
+    "lpbox_bqp_get_scalar": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]),
 }
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_long, C.c_void_p)

@@ -188,6 +188,22 @@ int lpbox_big_get_x(lpbox_big_t *h, double *out_local);                         
 int lpbox_big_get_vec(lpbox_big_t *h, const char *name, double *out, long cap); /* "x","z1","z2","pd" (local), "z4","Ex" (rows) */
 int lpbox_big_get_scalar(lpbox_big_t *h, const char *name, double *out);        /* "cur_obj","iter","stop","outer_total","pcg_total",... */
 
+/* ---- generic constrained binary QP: min x'Ax + b'x  s.t.  Cx = d, Ex <= f, x in {0,1}^n -----------------------------------------
+ * The reference's ADMM_bqp (Segmentation/.../LPboxADMMsolver.cpp:1384-1832) behind ADMM_bqp_unconstrained / _linear_eq / _linear_ineq /
+ * _linear_eq_and_uneq (:1834-2109; C++ only, not in the pyx).  Matrices are CSR with ascending columns; A must store every diagonal
+ * entry (the reference adds rho to A.diagonal() in place, :1483).  m = 0: no equality constraints, l = 0: no inequality constraints. */
+typedef struct lpbox_bqp lpbox_bqp_t;
+lpbox_bqp_t *lpbox_bqp_create(int device);
+void lpbox_bqp_destroy(lpbox_bqp_t *h);
+int lpbox_bqp_preset(lpbox_bqp_t *h, int type);      /* hyper-parameters of ADMM_bqp_{unconstrained,linear_eq,linear_ineq,linear_eq_and_uneq}_init (:587-672): 0,1,2,3 */
+int lpbox_bqp_set_params(lpbox_bqp_t *h, const double *p11);   /* stop_threshold, std_threshold, gamma_val, gamma_factor, rho_change_step, max_iters, initial_rho, history_size, learning_fact, pcg_tol, pcg_maxiters */
+int lpbox_bqp_set_problem(lpbox_bqp_t *h, int n, const int *Ap, const int *Ai, const double *Av, const double *b, const double *x0,
+                          int m, const int *Cp, const int *Ci, const double *Cv, const double *d,
+                          int l, const int *Ep, const int *Ei, const double *Ev, const double *f);
+int lpbox_bqp_solve(lpbox_bqp_t *h, int *iterations);          /* the whole ADMM_bqp loop; *iterations = the `iter` it ended on */
+int lpbox_bqp_get_vec(lpbox_bqp_t *h, const char *name, double *out, long cap);   /* Solution (LPh): "x" (x_sol), "y1", "y2", "best_sol"; also "z1","z2","z3","z4","y3" */
+int lpbox_bqp_get_scalar(lpbox_bqp_t *h, const char *name, double *out);          /* "iters","stop" (1 xyy, 2 obj_std, 0 max_iters),"cur_obj","best_bin_obj","total_pcg",... */
+
 #ifdef __cplusplus
 }
 #endif

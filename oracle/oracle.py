@@ -396,3 +396,89 @@ class SegOracle:
     @property
     def legacy_iter_plus1(self):
         return self.L.sego_legacy_iter_plus1(self.h)
+
+
+# ------------------------------------------------------------------------------------------------
+# generic constrained BQP (oracle/bqp_oracle.c: ADMM_bqp, SEGcpp:1384-1832)
+# ------------------------------------------------------------------------------------------------
+_bqp_bound = False
+
+
+def _bqp_lib():
+    global _bqp_bound
+    L = lib()
+    if _bqp_bound:
+        return L
+    vp = C.c_void_p
+    L.bqpo_create.restype = vp
+    L.bqpo_destroy.argtypes = [vp]
+    L.bqpo_set_order.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    L.bqpo_preset.argtypes = [vp, C.c_int]
+    L.bqpo_set_params.argtypes = [vp, _dp]
+    L.bqpo_set_problem.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp]
+    L.bqpo_solve.argtypes = [vp]
+    L.bqpo_get_vec.argtypes = [vp, C.c_char_p, _dp, C.c_int]
+    L.bqpo_get_scalar.argtypes = [vp, C.c_char_p]
+    L.bqpo_get_scalar.restype = C.c_double
+    L.bqpo_get_trace.argtypes = [vp, _ip, C.c_int]
+    _bqp_bound = True
+    return L
+
+
+def _csr_ptrs(M, keep):
+    """M = (rowptr, colidx, vals) or None -> ctypes pointers (arrays appended to `keep` so that they stay alive)."""
+    if M is None:
+        return None, None, None
+    p, i, v = (np.ascontiguousarray(M[0], np.int32), np.ascontiguousarray(M[1], np.int32), np.ascontiguousarray(M[2], np.float64))
+    keep += [p, i, v]
+    return p.ctypes.data_as(C.c_void_p), i.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p)
+
+
+class BqpOracle:
+    """problem: dict(n, A=(rowptr, colidx, vals), b, x0[, C=(...), d][, E=(...), f])."""
+
+    def __init__(self, problem, preset=None, params=None, order=ORDER_EIGEN, T=256, chunk=512):
+        self.L = _bqp_lib()
+        self.h = C.c_void_p(self.L.bqpo_create())
+        self.n = int(problem["n"])
+        self.m = len(problem["d"]) if problem.get("C") is not None else 0
+        self.l = len(problem["f"]) if problem.get("E") is not None else 0
+        keep = []
+        A = _csr_ptrs(problem["A"], keep)
+        Cm = _csr_ptrs(problem.get("C"), keep)
+        Em = _csr_ptrs(problem.get("E"), keep)
+        vec = lambda k: (keep.append(np.ascontiguousarray(problem[k], np.float64)) or keep[-1].ctypes.data_as(C.c_void_p)) if problem.get(k) is not None else None
+        rc = self.L.bqpo_set_problem(self.h, self.n, *A, vec("b"), vec("x0"), self.m, *Cm, vec("d"), self.l, *Em, vec("f"))
+        if rc:
+            raise ValueError(f"bqpo_set_problem failed: {rc}")
+        ptype = (1 if self.m else 0) | (2 if self.l else 0)
+        self.L.bqpo_preset(self.h, ptype if preset is None else int(preset))
+        if params is not None:
+            self.L.bqpo_set_params(self.h, np.ascontiguousarray(params, np.float64))
+        self.L.bqpo_set_order(self.h, order, T, chunk)
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.bqpo_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def solve(self):
+        return self.L.bqpo_solve(self.h)
+
+    def vec(self, name):
+        out = np.zeros(max(self.n, self.m, self.l, 1))
+        k = self.L.bqpo_get_vec(self.h, name.encode(), out, len(out))
+        if k < 0:
+            raise KeyError(name)
+        return out[:k].copy()
+
+    def scalar(self, name):
+        return self.L.bqpo_get_scalar(self.h, name.encode())
+
+    def pcg_trace(self):
+        out = np.zeros(20000, np.int32)
+        k = self.L.bqpo_get_trace(self.h, out, len(out))
+        return out[:k].copy()
