@@ -109,3 +109,29 @@ class BqpSolver:
     def solution(self):
         """The reference's Solution struct (LPh): x_sol, y1, y2, best_sol; the binary answer is x_sol >= 0.5."""
         return dict(x_sol=self.vec("x"), y1=self.vec("y1"), y2=self.vec("y2"), best_sol=self.vec("best_sol"))
+
+
+# ---- the reference's four entry points by name (SEGcpp:1834-2109); each returns the Solution dict -------------------------------
+def _run(n, A, b, x0, C_=None, d=None, E=None, f=None, preset=0, params=None, device=0):
+    s = BqpSolver(n, A, b, x0, C_, d, E, f, preset=preset, params=params, device=device)
+    it = s.solve()
+    sol = s.solution()
+    sol.update(iterations=it, stop=int(s.scalar("stop")), best_bin_obj=s.scalar("best_bin_obj"), time_elapsed_ms=s.scalar("kernel_ms"))
+    s.close()
+    return sol
+
+
+def ADMM_bqp_unconstrained(n, A, b, x0, **kw):
+    return _run(n, A, b, x0, preset=PRESET_UNCONSTRAINED, **kw)
+
+
+def ADMM_bqp_linear_eq(n, A, b, x0, m, C_, d, **kw):
+    return _run(n, A, b, x0, C_=C_, d=np.asarray(d)[:m], preset=PRESET_EQ, **kw)
+
+
+def ADMM_bqp_linear_ineq(n, A, b, x0, l, E, f, **kw):
+    return _run(n, A, b, x0, E=E, f=np.asarray(f)[:l], preset=PRESET_INEQ, **kw)
+
+
+def ADMM_bqp_linear_eq_and_uneq(n, A, b, x0, m, C_, d, l, E, f, **kw):
+    return _run(n, A, b, x0, C_=C_, d=np.asarray(d)[:m], E=E, f=np.asarray(f)[:l], preset=PRESET_EQ_INEQ, **kw)

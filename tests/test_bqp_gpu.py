@@ -108,3 +108,22 @@ def test_equality_and_mixed_types(kind):
     Cx = np.zeros(40)
     np.add.at(Cx, np.arange(600) % 40, g.vec("x"))
     assert np.abs(Cx - 1).max() < 0.5
+
+
+def test_named_entry_points_and_scipy_input():
+    import scipy.sparse as sp
+    from lpbox_hip import bqp
+    rs = np.random.RandomState(5)
+    n = 300
+    a, b = rs.uniform(0.5, 2.0, n), rs.uniform(-4, 2, n)
+    sol = bqp.ADMM_bqp_unconstrained(n, sp.diags(a).tocsr(), b, np.zeros(n))
+    clear = np.abs(a + b) > 0.3
+    assert np.array_equal((sol["x_sol"] >= 0.5)[clear], (a + b < 0)[clear]) and sol["stop"] in (1, 2)
+    # one-of-each-group: a scipy matrix WITHOUT stored diagonal is completed with explicit zeros
+    groups, per = 10, 4
+    n = groups * per
+    cost = rs.uniform(1, 2, n); pick = np.arange(groups) * per + rs.randint(per, size=groups); cost[pick] = 0.1
+    Cm = sp.csr_matrix((np.ones(n), (np.arange(n) // per, np.arange(n))), shape=(groups, n))
+    sol = bqp.ADMM_bqp_linear_eq(n, sp.csr_matrix((n, n)), cost, np.full(n, 1.0 / per), groups, Cm, np.ones(groups))
+    want = np.zeros(n); want[pick] = 1
+    assert np.array_equal((sol["x_sol"] >= 0.5).astype(float), want)
