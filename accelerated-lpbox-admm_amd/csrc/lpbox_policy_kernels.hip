@@ -212,7 +212,9 @@ __global__ void __launch_bounds__(PT) policy_body_kernel(PolicyArgs pa) {
                 for (int pair = wave; pair < POL_ATTN_PAIRS(VARS * 4); pair += PT / 64) {
                     const int v = pair >> 2, hh = pair & 3;
                     const int tok0 = v * TOK;
-                    const int off = (tok0 + r31) * LDQ + hh * 16 + 8 * hf;
+                    // rows past the variable's tokens only feed masked keys / unused queries; keep the read inside the image all the same
+                    const int qrow = (TOK * (VARS - 1) + 31 < QROWS) ? tok0 + r31 : min(tok0 + r31, QROWS - 1);
+                    const int off = qrow * LDQ + hh * 16 + 8 * hf;
                     const f16x8 ka = *(const f16x8 *)(S.u.a.k + off);        // A: row = key r31, k = 8 hf + e
                     const f16x8 qb = *(const f16x8 *)(S.u.a.q + off);        // B: col = query r31 (already scaled by 1/sqrt(16), mha.py:42)
                     // V^T fragments for the second product, requested now: element e of k-step s is key 16 s + 8 (e>>2) + 4 hf + (e&3)
