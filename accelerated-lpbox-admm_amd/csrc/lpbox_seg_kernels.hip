@@ -65,10 +65,24 @@ __device__ __forceinline__ double tm_row(const SegDev &d, int i, GET get) {
     double tmp = 0;
     const int len = d.rowlen[i];
     const double tdi = d.td[i];
-    for (int k = 0; k < len; k++) {
-        const int c = d.ecol[(size_t)k * d.n + i];
-        const double val = (c == i) ? tdi : 2 * d.eval[(size_t)k * d.n + i];
-        tmp += val * get(c);
+    if (d.ell_w <= 8) {
+        // rows of the image problems have <= 7 entries: fetch all indices, then all values, then all gathered elements before the
+        // (ordered) additions, so that the loads of one row are in flight together
+        int c[8]; double v[8], g[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) if (k < len) c[k] = d.ecol[(size_t)k * d.n + i];
+#pragma unroll
+        for (int k = 0; k < 8; k++) if (k < len) v[k] = d.eval[(size_t)k * d.n + i];
+#pragma unroll
+        for (int k = 0; k < 8; k++) if (k < len) g[k] = get(c[k]);
+#pragma unroll
+        for (int k = 0; k < 8; k++) if (k < len) tmp += ((c[k] == i) ? tdi : 2 * v[k]) * g[k];
+    } else {
+        for (int k = 0; k < len; k++) {
+            const int c = d.ecol[(size_t)k * d.n + i];
+            const double val = (c == i) ? tdi : 2 * d.eval[(size_t)k * d.n + i];
+            tmp += val * get(c);
+        }
     }
     double res = 0.0;
     res += 1.0 * tmp;
