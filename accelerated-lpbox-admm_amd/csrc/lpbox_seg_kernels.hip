@@ -423,11 +423,23 @@ __global__ void __launch_bounds__(T) seg_k_post(SegDev d, int in, int out) {
             // A x and A round(x) in one pass over the row (compute_cost :568-572, A_ptr restricted to the live variables)
             double t1 = 0, t2 = 0;
             const int len = d.rowlen[i];
-            for (int k = 0; k < len; k++) {
-                const int c = d.ecol[(size_t)k * d.n + i];
-                const double xc = x[c], a = d.eval[(size_t)k * d.n + i];
-                t1 += a * xc;
-                t2 += a * (xc >= 0.5 ? 1.0 : 0.0);                           // fixed variables hold x = 0
+            if (d.ell_w <= 8) {                                               // all loads of the row in flight together (cf. tm_row)
+                int c[8]; double a[8], xc[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) if (k < len) c[k] = d.ecol[(size_t)k * d.n + i];
+#pragma unroll
+                for (int k = 0; k < 8; k++) if (k < len) a[k] = d.eval[(size_t)k * d.n + i];
+#pragma unroll
+                for (int k = 0; k < 8; k++) if (k < len) xc[k] = x[c[k]];
+#pragma unroll
+                for (int k = 0; k < 8; k++) if (k < len) { t1 += a[k] * xc[k]; t2 += a[k] * (xc[k] >= 0.5 ? 1.0 : 0.0); }
+            } else {
+                for (int k = 0; k < len; k++) {
+                    const int c = d.ecol[(size_t)k * d.n + i];
+                    const double xc = x[c], a = d.eval[(size_t)k * d.n + i];
+                    t1 += a * xc;
+                    t2 += a * (xc >= 0.5 ? 1.0 : 0.0);                       // fixed variables hold x = 0
+                }
             }
             double Ax = 0.0; Ax += 1.0 * t1;
             double Axb = 0.0; Axb += 1.0 * t2;
