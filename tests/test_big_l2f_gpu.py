@@ -80,7 +80,8 @@ def _rank(rank, world, port, q, plan):
     dist.destroy_process_group()
 
 
-def test_two_rank_l2f_agrees_with_single_rank():
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_l2f_agrees_with_single_rank(world):
     import torch.multiprocessing as mp
     from lpbox_hip.big import BigLp
     from lpbox_hip.synth import make_auction_like
@@ -96,19 +97,19 @@ def test_two_rank_l2f_agrees_with_single_rank():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_rank, args=(r, 2, port, q, plan)) for r in range(2)]
+    procs = [ctx.Process(target=_rank, args=(r, world, port, q, plan)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert res[0][3] + res[1][3] == g.get_n() and res[0][5] == res[1][5] == g.scalar("n_live")
-    assert res[0][6] == res[1][6] == g.scalar("pcg_total")
-    x = np.concatenate([res[0][2], res[1][2]])
+    assert sum(r[3] for r in res) == g.get_n() and all(r[5] == g.scalar("n_live") for r in res)
+    assert all(r[6] == g.scalar("pcg_total") for r in res)
+    x = np.concatenate([r[2] for r in res])
     assert np.abs(x - g.local_x()).max() < 5e-4           # rounding x the PCG's error amplification (cf. test_big_gpu_parity)
-    assert res[0][7] == res[1][7] and abs(res[0][7] - g.scalar("sum_fix_obj")) <= 1e-9 * abs(g.scalar("sum_fix_obj"))
-    assert abs(res[0][4] - g.cal_Obj()) <= 1e-3 * abs(g.cal_Obj()) and res[0][4] == res[1][4]
+    assert all(r[7] == res[0][7] for r in res) and abs(res[0][7] - g.scalar("sum_fix_obj")) <= 1e-9 * abs(g.scalar("sum_fix_obj"))
+    assert abs(res[0][4] - g.cal_Obj()) <= 1e-3 * abs(g.cal_Obj()) and all(r[4] == res[0][4] for r in res)
 
 
 def test_product_loop_on_the_big_path_matches_oracle_loop():
