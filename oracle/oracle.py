@@ -33,8 +33,7 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB):
-        build()
+    build()                     # (re)builds only when the library is missing or older than its sources
     L = C.CDLL(LIB)
     L.lpo_create.restype = C.c_void_p
     L.lpo_create.argtypes = [C.c_int]

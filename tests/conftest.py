@@ -12,6 +12,18 @@ for p in (ROOT, PKG):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    _build_if_stale()
+
+
+def _build_if_stale():
+    """A fresh checkout has no liblpbox_hip.so (it is git-ignored): build it, as __graft_entry__.build() would.  Nothing is rebuilt
+    when the library is newer than its sources (the state gpurun ships to the GPU box)."""
+    import subprocess
+    csrc = os.path.join(PKG, "csrc")
+    lib = os.path.join(PKG, "lpbox_hip", "liblpbox_hip.so")
+    srcs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h"))] + [os.path.join(ROOT, "include", "lpbox_hip.h")]
+    if not os.path.exists(lib) or any(os.path.getmtime(s) > os.path.getmtime(lib) for s in srcs):
+        subprocess.check_call(["make", "-s", "-C", csrc, "all"])
 
 
 def _gpu_available():
