@@ -61,3 +61,30 @@ def test_square_instance_is_refused_loudly():
     I["b"] = -np.ones(8)
     with pytest.raises(LpboxError, match="n == l"):
         LpBatch([I])
+
+
+def test_handles_driven_from_different_threads():
+    """One handle = one stream; different handles may be driven concurrently from different threads (ctypes releases the GIL): the
+    results are those of the sequential runs, bit for bit."""
+    import threading
+    insts = lp_instances("lp_100_500_seed0.npz")
+    groups = [insts[0:16], insts[16:32], insts[32:48], insts[48:64]]
+
+    def solve(g):
+        b = LpBatch(g)
+        b.solve_init()
+        b.solve_iter(0, 3000)
+        return [b.debug_vec("x", i) for i in range(b.B)], [b.counters(i) for i in range(b.B)]
+    seq = [solve(g) for g in groups]
+    out = [None] * len(groups)
+
+    def run(k):
+        out[k] = solve(groups[k])
+    th = [threading.Thread(target=run, args=(k,)) for k in range(len(groups))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for k in range(len(groups)):
+        assert out[k][1] == seq[k][1]
+        assert all(bits_equal(a, b) for a, b in zip(out[k][0], seq[k][0]))
