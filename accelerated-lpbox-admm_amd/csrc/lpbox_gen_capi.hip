@@ -268,6 +268,9 @@ int lpbox_bqp_solve(lpbox_bqp_t *h, int *iterations) {                          
         for (int it = 0; it < batch; it++) CHK(enqueue_iteration(h, d));
         HIPCHK(gen_launch_prep(d, 0, &h->parity, h->stream)); h->launches++;          // finalise the last iteration of the batch
     }
+    // best_sol = x_sol of the last improving iteration (:1792) is copied by the NEXT iteration's y kernel; if the loop ended right after an
+    // improvement, do it here (x is not touched after the halt)
+    if (h->hst.copy_best) HIPCHK(hipMemcpyAsync(h->best.p, h->x.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     float ms = 0.f;

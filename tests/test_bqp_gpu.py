@@ -127,3 +127,16 @@ def test_named_entry_points_and_scipy_input():
     sol = bqp.ADMM_bqp_linear_eq(n, sp.csr_matrix((n, n)), cost, np.full(n, 1.0 / per), groups, Cm, np.ones(groups))
     want = np.zeros(n); want[pick] = 1
     assert np.array_equal((sol["x_sol"] >= 0.5).astype(float), want)
+
+
+def test_best_sol_when_the_loop_ends_on_an_improving_iteration():
+    """max_iters chosen so that the last iteration run still improves best_bin_obj: best_sol must be that iteration's x_sol."""
+    P = _random_problem(300, 20, 30, 7)
+    P.pop("E"); P.pop("f")
+    hit = 0
+    for mi in (1, 2, 3, 4, 6, 9):
+        prm = [1e-4, 1e-6, 1.6, 0.95, 5, mi, 1, 3, 1.05, 1e-4, 1000]
+        g, o, it_g, it_o = _pair(P, params=prm)
+        assert it_g == it_o and bits_equal(g.vec("best_sol"), o.vec("best_sol")) and bits_equal(g.vec("x"), o.vec("x"))
+        hit += bits_equal(o.vec("best_sol"), o.vec("x"))
+    assert hit > 0            # at least one of the runs ended on an improving iteration (best_sol == x_sol)
