@@ -625,6 +625,8 @@ int lpbox_iterate_l2f(lpbox_t *h, int iter_start, int iter_end, const double *ve
                       int *rets) {
     if (valid_handle(h) && h->seg) {
         int ret = 0;
+        if (nums && nums[0] != 0 && vec_stride < segc_get_n(h->seg))
+            return fail(LPBOX_E_BADARG, "fix vector holds %ld entries, %d live variables", vec_stride, segc_get_n(h->seg));
         int rc = segc_l2f(h->seg, iter_start, iter_end, vec, nums ? nums[0] : 0, &ret);
         if (rc < 0) return rc;
         if (rets) rets[0] = ret;
@@ -650,6 +652,7 @@ int lpbox_iterate_l2f(lpbox_t *h, int iter_start, int iter_end, const double *ve
         if (num < 0 || num > n_live) return fail(LPBOX_E_BADARG, "instance %zu: fix count %d outside [0,%d]", i, num, n_live);
         if (num != 0) {
             if (!vec) return fail(LPBOX_E_BADARG, "fix vector missing");
+            if (vec_stride < n_live) return fail(LPBOX_E_BADARG, "instance %zu: fix vector holds %ld entries, %d live variables", i, vec_stride, n_live);
             const double *v = vec + (size_t)i * vec_stride;
             int cnt = 0;
             for (int q = 0; q < n_live; q++) if (v[q] == 1 || v[q] == 0) cnt++;
