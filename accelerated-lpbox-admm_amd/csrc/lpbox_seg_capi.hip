@@ -173,6 +173,7 @@ int upload(SegSolver *s) {
     if (rc) return rc;
     const int n = s->n;
     s->EPT = 2;
+    if (const char *e = getenv("LPBOX_SEG_EPT")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) s->EPT = v; }   // tuning only
     while ((n + SEG_T * s->EPT - 1) / (SEG_T * s->EPT) > 2 * SEG_T && s->EPT < 64) s->EPT *= 2;   // keep G <= 512 partials
     s->G = (n + SEG_T * s->EPT - 1) / (SEG_T * s->EPT);
     if (s->G > 2 * SEG_T) return lpbox_fail(LPBOX_E_UNSUPPORTED, "n = %d is beyond the two-level reduction of the segmentation kernels", n);
