@@ -12,7 +12,7 @@ import time
 
 import numpy as np
 
-from . import _lib
+from . import _lib, files
 from ._lib import LpboxError, check  # noqa: F401
 
 STOP_NAMES = {0: None, 1: "y1_y2", 2: "obj_std", 3: "pcg_alpha_negative", 4: "all_fixed"}
@@ -291,13 +291,10 @@ class PyLPboxADMMsolver:
         reason, p1 = self._b.stop(0)
         if dump:
             done = (p1 - i) if reason in (1, 2) else (j - i)           # iterations this call ran (break leaves iter at the stop)
-            with open(os.path.join(out_dir, "%d_%d_xiters_%d.csv" % (k, jj, fi)), "w") as f:      # "w+" (LPcpp:778)
-                X = self._b.get_x_iters_2d(j - i, 0)[:, :done].T       # one row per iteration
-                rows = range(done) if self.print_info == 2 else (range(done - 1, done) if reason in (1, 2) else range(0))
-                for r in rows:
-                    f.write("Iter%d," % (i + r + 1) + ",".join("%f" % v for v in X[r]) + "\n")
-        with open(os.path.join(out_dir, "allres.csv"), "a") as f:      # "%d,%f,%d,%f" (LPcpp:1081)
-            f.write("%d,%f,%d,%f\n" % (fi, -self._b.cur_bin_obj(0), p1, secs))
+            X = self._b.get_x_iters_2d(j - i, 0)[:, :done].T           # one row per iteration
+            lo = 0 if self.print_info == 2 else (done - 1 if reason in (1, 2) else done)   # 3: only the iterate of the stop
+            files.write_xiters_csv(os.path.join(out_dir, "%d_%d_xiters_%d.csv" % (k, jj, fi)), X[lo:done], i + lo)
+        files.append_allres(os.path.join(out_dir, "allres.csv"), fi, -self._b.cur_bin_obj(0), p1, secs)
 
     # LP pyx:25-26
     def cal_Obj(self):

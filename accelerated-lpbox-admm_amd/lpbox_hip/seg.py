@@ -11,7 +11,7 @@ import time
 
 import numpy as np
 
-from . import _lib
+from . import _lib, files
 from ._lib import LpboxError, check  # noqa: F401
 from .lp import _as_int
 
@@ -105,8 +105,7 @@ class PyLPboxADMMsolver:
             self._write_xiters(os.path.join(xdir, "%d.csv" % self.problem))
         if rdir:
             obj, c = self.debug_scalar("cur_obj"), self.debug_scalar("c")
-            with open(os.path.join(rdir, "xiter_all.csv"), "a") as f:          # "%d,%f,%f,%d,%f" (SEGcpp:1376)
-                f.write("%d,%f,%f,%d,%f\n" % (self.problem, obj, obj + c, self.stop()[1], ms * 1.0 / 1000))
+            files.append_xiter_all(os.path.join(rdir, "xiter_all.csv"), self.problem, obj, obj + c, self.stop()[1], ms * 1.0 / 1000)
         return e.value
 
     def _out_dir(self, d):
@@ -125,10 +124,7 @@ class PyLPboxADMMsolver:
         return out
 
     def _write_xiters(self, path):
-        X = self.x_history()
-        with open(path, "w") as f:                                              # "Iter%d,%lf,...,%lf" (SEGcpp:1270-1277)
-            for r in range(X.shape[0]):
-                f.write("Iter%d," % (r + 1) + ",".join(map("%f".__mod__, X[r])) + "\n")
+        files.write_xiters_csv(path, self.x_history())                          # "Iter%d,%lf,...,%lf" (SEGcpp:1270-1277)
 
     # SEG pyx:23-24
     def solve_iter_l2f(self, i, j, vec, num):
