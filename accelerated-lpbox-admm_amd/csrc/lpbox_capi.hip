@@ -58,6 +58,10 @@ struct LpInstance {
     std::vector<int> rowptr, colidx;   // CSR of the same matrix
     std::vector<int> cpos, cperm;      // storage layout: variable j sits at position cpos[j]; cperm[pos] = j
     std::vector<int> rowG;             // lanes that share the sum of row r (1,2,4,8)
+    std::vector<int> col_own;          // entries of column j summed by its own lane (= its length unless the column is split)
+    std::vector<int> col_help;         // [4*j + q]: entries of column j summed by lane q of its quad as a helper (0 = none)
+    struct Help { int var, first, count; };
+    std::vector<Help> help_of_pos;     // storage position -> helper chunk (var < 0: none)
     std::vector<double> b, f_org;
     // early-fix bookkeeping (LPcpp:1192-1206): original index of each live variable, in compact order
     std::vector<int> left_idx;
@@ -95,8 +99,8 @@ struct lpbox_solver {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double kernel_ms = 0.0;
     long long launches = 0;
-    DevBuf<int> rs_ptr, cs_ptr, isc, ctl, left_idx, xi_rows;
-    DevBuf<uint16_t> rs_col, cs_row, rid, rmeta, rgl;
+    DevBuf<int> rs_ptr, cs_ptr, hs_ptr, isc, ctl, left_idx, xi_rows;
+    DevBuf<uint16_t> rs_col, cs_row, rid, rmeta, rgl, cmeta;
     DevBuf<double> x, z1, z2, b, pd, z4, f, f_org, dsc, hist, dctl, c1_init, xhist, xi_out;
     DevBuf<uint8_t> live, newfix, live_init;
     DevBuf<unsigned long long> stamps;
@@ -112,7 +116,7 @@ struct lpbox_solver {
     LpBatchDev dev() const {
         LpBatchDev d;
         d.B = B; d.NS = NS; d.LS = LS; d.ZS = ZS;
-        d.rs_ptr = rs_ptr.p; d.rs_col = rs_col.p; d.cs_ptr = cs_ptr.p; d.cs_row = cs_row.p; d.rid = rid.p; d.rmeta = rmeta.p; d.rgl = rgl.p;
+        d.rs_ptr = rs_ptr.p; d.rs_col = rs_col.p; d.cs_ptr = cs_ptr.p; d.cs_row = cs_row.p; d.hs_ptr = hs_ptr.p; d.cmeta = cmeta.p; d.rid = rid.p; d.rmeta = rmeta.p; d.rgl = rgl.p;
         d.x = x.p; d.z1 = z1.p; d.z2 = z2.p; d.b = b.p; d.pd = pd.p; d.live = live.p; d.newfix = newfix.p;
         d.z4 = z4.p; d.f = f.p; d.dsc = dsc.p; d.isc = isc.p; d.hist = hist.p;
         d.ctl = ctl.p; d.dctl = dctl.p; d.xhist = xhist.p; d.ws_cap = ws_cap; d.stamps = stamps.p;
@@ -177,7 +181,7 @@ int finalize(lpbox_t *h) {
     if (!h->stream) HIPCHK(hipStreamCreate(&h->stream));
     if (!h->ev0) { HIPCHK(hipEventCreate(&h->ev0)); HIPCHK(hipEventCreate(&h->ev1)); }
     const size_t B = h->B, NS = h->NS, LS = h->LS, ZS = h->ZS;
-    HIPCHK(h->rs_ptr.alloc(B * (NS + 1))); HIPCHK(h->cs_ptr.alloc(B * (NS + 1)));
+    HIPCHK(h->rs_ptr.alloc(B * (NS + 1))); HIPCHK(h->cs_ptr.alloc(B * (NS + 1))); HIPCHK(h->hs_ptr.alloc(B * (NS + 1))); HIPCHK(h->cmeta.alloc(B * NS));
     HIPCHK(h->rs_col.alloc(B * ZS)); HIPCHK(h->cs_row.alloc(B * ZS)); HIPCHK(h->rid.alloc(B * NS)); HIPCHK(h->rmeta.alloc(B * NS)); HIPCHK(h->rgl.alloc(B * NS));
     HIPCHK(h->live_init.alloc(B * NS));
     HIPCHK(h->x.alloc(B * NS)); HIPCHK(h->z1.alloc(B * NS)); HIPCHK(h->z2.alloc(B * NS));
@@ -191,8 +195,8 @@ int finalize(lpbox_t *h) {
     HIPCHK(h->stamps.alloc(B * 16)); HIPCHK(hipMemset(h->stamps.p, 0, B * 16 * sizeof(unsigned long long)));
 #endif
 
-    std::vector<int> h_rs_ptr(B * (NS + 1), 0), h_cs_ptr(B * (NS + 1), 0), h_isc(B * NI_COUNT, 0);
-    std::vector<uint16_t> h_rs_col(B * ZS, 0), h_cs_row(B * ZS, 0), h_rid(B * NS, 0xFFFF), h_rgl(B * NS, 0), h_rmeta(B * NS, 0x10);
+    std::vector<int> h_rs_ptr(B * (NS + 1), 0), h_cs_ptr(B * (NS + 1), 0), h_hs_ptr(B * (NS + 1), 0), h_isc(B * NI_COUNT, 0);
+    std::vector<uint16_t> h_rs_col(B * ZS, 0), h_cs_row(B * ZS, 0), h_rid(B * NS, 0xFFFF), h_rgl(B * NS, 0), h_rmeta(B * NS, 0x10), h_cmeta(B * NS, 0);
     std::vector<uint8_t> h_live(B * NS, 0);
     std::vector<double> h_b(B * NS, 0.0), h_f(B * LS, 0.0), h_c1(B, 0.0);
     const bool nosort = getenv("LPBOX_LP_NOSORT") != nullptr;
@@ -253,14 +257,14 @@ int finalize(lpbox_t *h) {
             std::stable_sort(I.cperm.begin(), I.cperm.end(), [&](int a, int c) {
                 return I.colptr[a + 1] - I.colptr[a] > I.colptr[c + 1] - I.colptr[c]; });
         std::vector<int> var_of_pos(NS, -1);
-        if (nosort || noconflict) {
-            for (int qq = 0; qq < I.n; qq++) {
-                const int p = nosort ? qq : block_base(qq / 64) + qq % 64;
-                I.cpos[I.cperm[qq]] = p; var_of_pos[p] = I.cperm[qq];
-            }
-        } else {
-            // occurrences of column j in the row-gather instructions: (half-wave group of the task slot, entry index k)
-            std::vector<std::vector<std::pair<int, int>>> occ(I.n);
+        auto clen = [&](int j) { return j < 0 ? 0 : I.colptr[j + 1] - I.colptr[j]; };
+        I.col_own.assign(I.n, 0); I.col_help.assign((size_t)4 * I.n, 0);
+        for (int j = 0; j < I.n; j++) I.col_own[j] = clen(j);
+        // occurrences of column j in the row-gather instructions: (half-wave group of the task slot, entry index k)
+        std::vector<std::vector<std::pair<int, int>>> occ(I.n);
+        const int ngrp = (int)NS / 32;
+        std::vector<int> cnt((size_t)ngrp * max_chain * 32, 0);
+        if (!nosort && !noconflict)
             for (int r = 0; r < I.l; r++) {
                 const int G = I.rowG[r];
                 for (int e = I.rowptr[r]; e < I.rowptr[r + 1]; e++) {
@@ -268,8 +272,19 @@ int finalize(lpbox_t *h) {
                     occ[I.colidx[e]].push_back({(slot_of_row[r] + ee % G) / 32, ee / G});
                 }
             }
-            const int ngrp = (int)NS / 32;
-            std::vector<int> cnt((size_t)ngrp * max_chain * 32, 0);
+        auto place_cost = [&](int j, int c) { long cost = 0; for (auto &o : occ[j]) cost += cnt[((size_t)o.first * max_chain + o.second) * 32 + c]; return cost; };
+        auto place_commit = [&](int j, int p) {
+            for (auto &o : occ[j]) cnt[((size_t)o.first * max_chain + o.second) * 32 + (p % 32)]++;
+            I.cpos[j] = p; var_of_pos[p] = j;
+        };
+        const bool colsplit = h->EPT == 1 && !nosort && getenv("LPBOX_LP_NOCOLSPLIT") == nullptr;
+        if (nosort) {
+            for (int qq = 0; qq < I.n; qq++) { I.cpos[I.cperm[qq]] = qq; var_of_pos[qq] = I.cperm[qq]; }
+        } else if (!colsplit) {
+            // Blocks of 64 by decreasing column length (stable) are dealt to the waves; INSIDE a block the lane (= LDS bank class
+            // pos % 32 of the variable in the gathered vector) is chosen greedily so that the 32 lanes of a half-wave gather from
+            // different banks in as many row-gather instructions as possible (an instruction = the k-th list entry of the 32 row
+            // tasks of one half-wave).
             for (int blk = 0; blk * 64 < I.n; blk++) {
                 bool used[64] = {false};
                 const int base = block_base(blk);
@@ -278,14 +293,79 @@ int finalize(lpbox_t *h) {
                     int best = -1; long best_cost = 0;
                     for (int c = 0; c < 32; c++) {
                         if (used[c] && used[c + 32]) continue;
-                        long cost = 0;
-                        for (auto &o : occ[j]) cost += cnt[((size_t)o.first * max_chain + o.second) * 32 + c];
+                        const long cost = noconflict ? 0 : place_cost(j, c);
                         if (best < 0 || cost < best_cost) { best = c; best_cost = cost; }
                     }
                     const int lane = used[best] ? best + 32 : best;
                     used[lane] = true;
-                    for (auto &o : occ[j]) cnt[((size_t)o.first * max_chain + o.second) * 32 + best]++;
-                    I.cpos[j] = base + lane; var_of_pos[base + lane] = j;
+                    place_commit(j, base + lane);
+                }
+            }
+        } else {
+            // One slot per thread: the per-wave issue rate of LDS gathers, not the LDS array, bounds a sparse product, so what
+            // counts is the LONGEST list of a wave.  Columns are grouped in quads of adjacent lanes, one long column with three
+            // short ones (long ranks ascending meet short ranks descending, so the quads of a wave look alike): the long column
+            // keeps its first tau entries (tau = longest companion), the rest is dealt in consecutive chunks to the other three
+            // lanes (helper lists, summed into a second accumulator and combined over the quad, lp_window_kernel cols_gather).
+            const int Q = (int)NS / 4, QW = 16, CH = 8;           // quads, quads per wave, register capacity of a helper list
+            auto var_of_rank = [&](int r) { return r < I.n ? I.cperm[r] : -1; };
+            struct Quad { int v[4]; int tau, tail, slot; };
+            std::vector<Quad> quad(Q);
+            std::vector<int> quad_of_var(I.n, -1);
+            auto r2 = [](int v) { return (v + 1) & ~1; };
+            for (int w = 0; w < Q / QW; w++) {
+                int A = 0, Bm = 0, Lm = 0;
+                for (int qi = 0; qi < QW; qi++) {
+                    Quad &qd = quad[w * QW + qi];
+                    qd.v[0] = var_of_rank(w * QW + qi);
+                    for (int t = 0; t < 3; t++) qd.v[1 + t] = var_of_rank((int)NS - 1 - (3 * (w * QW + qi) + t));
+                    const int L = clen(qd.v[0]);
+                    const int s1 = std::max(clen(qd.v[1]), std::max(clen(qd.v[2]), clen(qd.v[3])));
+                    qd.tau = std::min(L, std::max(s1, L - 3 * CH));
+                    qd.tail = L - qd.tau; qd.slot = -1;
+                    A = std::max(A, std::max(qd.tau, s1)); Bm = std::max(Bm, (qd.tail + 2) / 3); Lm = std::max(Lm, std::max(L, s1));
+                    for (int t = 0; t < 4; t++) if (qd.v[t] >= 0) quad_of_var[qd.v[t]] = w * QW + qi;
+                }
+                if (r2(A) + r2(Bm) + 1 >= r2(Lm))                 // splitting does not shorten this wave's longest list
+                    for (int qi = 0; qi < QW; qi++) { Quad &qd = quad[w * QW + qi]; qd.tau = clen(qd.v[0]); qd.tail = 0; }
+            }
+            // lane of every column: bank-aware greedy as above, inside the wave's free quad slots / the quad's free lanes
+            std::vector<char> used(NS, 0), slot_used(Q, 0);
+            for (int qq = 0; qq < I.n; qq++) {
+                const int j = I.cperm[qq];
+                Quad &qd = quad[quad_of_var[j]];
+                const int w = quad_of_var[j] / QW;
+                int best = -1; long best_cost = 0;
+                for (int t = (qd.slot >= 0 ? qd.slot : w * QW); t < (qd.slot >= 0 ? qd.slot + 1 : (w + 1) * QW); t++) {
+                    if (qd.slot < 0 && slot_used[t]) continue;
+                    for (int p = 4 * t; p < 4 * t + 4; p++) {
+                        if (used[p]) continue;
+                        const long cost = noconflict ? 0 : place_cost(j, p % 32);
+                        if (best < 0 || cost < best_cost) { best = p; best_cost = cost; }
+                    }
+                }
+                if (qd.slot < 0) { qd.slot = best / 4; slot_used[qd.slot] = 1; }
+                used[best] = 1;
+                place_commit(j, best);
+            }
+            for (int qd_i = 0; qd_i < Q; qd_i++) {               // quads made of holes only still need a slot (nothing is stored there)
+                Quad &qd = quad[qd_i];
+                if (qd.slot >= 0) continue;
+                for (int t = (qd_i / QW) * QW; t < (qd_i / QW + 1) * QW; t++) if (!slot_used[t]) { qd.slot = t; slot_used[t] = 1; break; }
+            }
+            // chunks of the tails, in lane order over the helper lanes of the quad
+            I.help_of_pos.assign(NS, {-1, 0, 0});
+            for (auto &qd : quad) {
+                if (qd.tail <= 0 || qd.v[0] < 0) continue;
+                const int jl = qd.v[0], pl = I.cpos[jl];
+                I.col_own[jl] = qd.tau;
+                int given = 0, hl = 0;
+                for (int p = 4 * qd.slot; p < 4 * qd.slot + 4; p++) {
+                    if (p == pl) continue;
+                    const int c = qd.tail / 3 + (hl < qd.tail % 3 ? 1 : 0);
+                    I.help_of_pos[p] = {jl, qd.tau + given, c};
+                    I.col_help[(size_t)4 * jl + (p - 4 * qd.slot)] = c;
+                    given += c; hl++;
                 }
             }
         }
@@ -297,27 +377,33 @@ int finalize(lpbox_t *h) {
             int max_col = 1;
             for (int j = 0; j < I.n; j++) max_col = std::max(max_col, I.colptr[j + 1] - I.colptr[j]);
             const int ngrp = (int)NS / 32, cap = (int)LS / 32;
-            std::vector<int> cnt((size_t)ngrp * max_col * 32, 0), usedc(32, 0);
+            std::vector<int> cnt((size_t)ngrp * 2 * max_col * 32, 0), usedc(32, 0);
             std::vector<int> order(I.l);
             for (int r = 0; r < I.l; r++) order[r] = r;
             std::stable_sort(order.begin(), order.end(), [&](int a, int c) { return I.rowptr[a + 1] - I.rowptr[a] > I.rowptr[c + 1] - I.rowptr[c]; });
-            // rank of row r inside column j's (ascending) row list = its entry index in the column gather
-            auto rank_in_col = [&](int j, int r) { return (int)(std::lower_bound(I.rowidx.begin() + I.colptr[j], I.rowidx.begin() + I.colptr[j + 1], r) - (I.rowidx.begin() + I.colptr[j])); };
+            // the column-gather instruction that reads row r for column j: (half-wave group of the reading lane, entry index in its
+            // list); helper lists are separate instructions, numbered after the own lists
+            auto instr_of = [&](int j, int r) {
+                const int rank = (int)(std::lower_bound(I.rowidx.begin() + I.colptr[j], I.rowidx.begin() + I.colptr[j + 1], r) - (I.rowidx.begin() + I.colptr[j]));
+                if (rank < I.col_own[j]) return (size_t)(I.cpos[j] / 32) * 2 * max_col + rank;
+                int first = I.col_own[j];
+                const int q0 = I.cpos[j] & ~3;
+                for (int q = 0; q < 4; q++) {
+                    const int c = I.col_help[(size_t)4 * j + q];
+                    if (rank < first + c) return (size_t)((q0 + q) / 32) * 2 * max_col + max_col + (rank - first);
+                    first += c;
+                }
+                return (size_t)0;
+            };
             for (int r : order) {
                 int best = -1; long best_cost = 0;
                 for (int c = 0; c < 32; c++) {
                     if (usedc[c] >= cap) continue;
                     long cost = 0;
-                    for (int e = I.rowptr[r]; e < I.rowptr[r + 1]; e++) {
-                        const int j = I.colidx[e];
-                        cost += cnt[((size_t)(I.cpos[j] / 32) * max_col + rank_in_col(j, r)) * 32 + c];
-                    }
+                    for (int e = I.rowptr[r]; e < I.rowptr[r + 1]; e++) cost += cnt[instr_of(I.colidx[e], r) * 32 + c];
                     if (best < 0 || cost < best_cost) { best = c; best_cost = cost; }
                 }
-                for (int e = I.rowptr[r]; e < I.rowptr[r + 1]; e++) {
-                    const int j = I.colidx[e];
-                    cnt[((size_t)(I.cpos[j] / 32) * max_col + rank_in_col(j, r)) * 32 + best]++;
-                }
+                for (int e = I.rowptr[r]; e < I.rowptr[r + 1]; e++) cnt[instr_of(I.colidx[e], r) * 32 + best]++;
                 rpos[r] = best + 32 * usedc[best]++;
             }
         }
@@ -325,11 +411,19 @@ int finalize(lpbox_t *h) {
             h_cs_ptr[i * (NS + 1) + p] = k;
             const int j = var_of_pos[p];
             if (j < 0) continue;
-            for (int e = I.colptr[j]; e < I.colptr[j + 1]; e++) h_cs_row[i * ZS + k++] = (uint16_t)rpos[I.rowidx[e]];
+            for (int e = I.colptr[j]; e < I.colptr[j] + I.col_own[j]; e++) h_cs_row[i * ZS + k++] = (uint16_t)rpos[I.rowidx[e]];
             h_b[i * NS + p] = I.b[j];
             h_live[i * NS + p] = 1;
+            h_cmeta[i * NS + p] = (uint16_t)(clen(j) | (I.col_own[j] < clen(j) ? 0x8000 : 0));
         }
         h_cs_ptr[i * (NS + 1) + NS] = k;
+        for (size_t p = 0; p < NS; p++) {                          // helper chunks follow the own parts in the same index pool
+            h_hs_ptr[i * (NS + 1) + p] = k;
+            if (I.help_of_pos.empty() || I.help_of_pos[p].var < 0) continue;
+            const auto &hp = I.help_of_pos[p];
+            for (int e = I.colptr[hp.var] + hp.first; e < I.colptr[hp.var] + hp.first + hp.count; e++) h_cs_row[i * ZS + k++] = (uint16_t)rpos[I.rowidx[e]];
+        }
+        h_hs_ptr[i * (NS + 1) + NS] = k;
         k = 0;
         for (size_t tp = 0; tp < NS; tp++) {
             h_rs_ptr[i * (NS + 1) + tp] = k;
@@ -351,6 +445,8 @@ int finalize(lpbox_t *h) {
     HIPCHK(hipMemcpy(h->live_init.p, h_live.data(), h_live.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->rs_ptr.p, h_rs_ptr.data(), h_rs_ptr.size() * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->cs_ptr.p, h_cs_ptr.data(), h_cs_ptr.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->hs_ptr.p, h_hs_ptr.data(), h_hs_ptr.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->cmeta.p, h_cmeta.data(), h_cmeta.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->rs_col.p, h_rs_col.data(), h_rs_col.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->cs_row.p, h_cs_row.data(), h_cs_row.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->rid.p, h_rid.data(), h_rid.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
@@ -473,7 +569,7 @@ void lpbox_destroy(lpbox_t *h) {
     if (h->seg) { segc_destroy(h->seg); delete h; return; }
     if (h->finalized) (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    h->rs_ptr.release(); h->cs_ptr.release(); h->isc.release(); h->ctl.release(); h->left_idx.release(); h->xi_rows.release();
+    h->rs_ptr.release(); h->cs_ptr.release(); h->hs_ptr.release(); h->cmeta.release(); h->isc.release(); h->ctl.release(); h->left_idx.release(); h->xi_rows.release();
     h->rs_col.release(); h->cs_row.release(); h->rid.release(); h->rmeta.release(); h->rgl.release(); h->live_init.release();
     h->x.release(); h->z1.release(); h->z2.release(); h->b.release(); h->pd.release(); h->z4.release(); h->f.release();
     h->f_org.release(); h->dsc.release(); h->hist.release(); h->dctl.release(); h->c1_init.release(); h->xhist.release();
@@ -935,6 +1031,18 @@ int lpbox_get_row_split(lpbox_t *h, int idx, int *lanes_of_row) {
     const LpInstance &I = h->inst[idx];
     for (int r = 0; r < I.l; r++) lanes_of_row[r] = I.rowG[r];
     return I.l;
+}
+
+int lpbox_get_col_split(lpbox_t *h, int idx, int *own, int *help4) {
+    int rc = check_idx(h, idx);
+    if (rc) return rc;
+    rc = finalize(h);
+    if (rc) return rc;
+    if (!own || !help4) return fail(LPBOX_E_BADARG, "null output");
+    const LpInstance &I = h->inst[idx];
+    for (int j = 0; j < I.n; j++) own[j] = I.col_own[j];
+    for (int k = 0; k < 4 * I.n; k++) help4[k] = I.col_help[k];
+    return I.n;
 }
 
 int lpbox_get_counters(lpbox_t *h, int idx, long long *outer_iters, long long *pcg_iters) {

@@ -116,6 +116,7 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double *red, int &par
         }
     }
     __syncthreads();
+#ifdef LPBOX_STAGE2_DPP
     double t[NV];
 #pragma unroll
     for (int k = 0; k < NV; k++) t[k] = buf[k * RED_MAXW + (lane & (W - 1))];
@@ -128,6 +129,25 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double *red, int &par
         if (W >= 16) u = u + dpp_mov<0x140>(u);      // 16 waves
         v[k] = u;
     }
+#else
+    // every lane reads all W wave partials (same address in all lanes: an LDS broadcast) and adds them in registers in the
+    // balanced tree over the wave index -- pairs (0,1) (2,3) ..., quads, ... -- i.e. the association of the xor butterfly the
+    // first version ran on DPP (floating-point addition is commutative, so the bits are identical), without its dependent
+    // cross-lane steps.
+    double t[NV][W];
+#pragma unroll
+    for (int k = 0; k < NV; k++)
+#pragma unroll
+        for (int w2 = 0; w2 < W; w2++) t[k][w2] = buf[k * RED_MAXW + w2];
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+#pragma unroll
+        for (int span = 1; span < W; span <<= 1)
+#pragma unroll
+            for (int w2 = 0; w2 < W; w2 += 2 * span) t[k][w2] = t[k][w2] + t[k][w2 + span];
+        v[k] = t[k][0];
+    }
+#endif
     parity ^= 1;
 }
 

@@ -48,7 +48,9 @@ struct LpBatchDev {
     // structure, in STORAGE order: variables sit at positions (columns of E sorted by decreasing length), row slots
     // likewise hold rows by decreasing length (rid[slot] = original row id; l-vectors stay indexed by original row id)
     const int *rs_ptr; const uint16_t *rs_col;   // row slot q: positions of its columns, ascending ORIGINAL column index
-    const int *cs_ptr; const uint16_t *cs_row;   // position p: original row ids of its column, ascending
+    const int *cs_ptr; const uint16_t *cs_row;   // position p: storage indices of the rows of its column's OWN part, ascending row id
+    const int *hs_ptr;                           // position p: its helper chunk of the long column of its quad of lanes (entries in cs_row too)
+    const uint16_t *cmeta;                       // position p: column length | 0x8000 if p owns its quad's split column
     const uint16_t *rid;      // row-task slot -> original row id (0xFFFF = no task)
     const uint16_t *rgl;      // row-task slot -> storage index of the row inside the gathered LDS l-vectors (bank-conflict aware)
     const uint16_t *rmeta;    // row-task slot -> (G << 4) | g: lane g of the G lanes sharing the row

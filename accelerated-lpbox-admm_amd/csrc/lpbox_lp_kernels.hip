@@ -46,7 +46,7 @@ namespace {
 // LDS carve-up shared by the launcher (size) and the kernel (pointers)
 // ------------------------------------------------------------------------------------------------
 struct LdsLayout {
-    size_t gx, gl, red, rs_ptr, cs_ptr, rs_col, cs_row, total;
+    size_t gx, gl, red, rs_ptr, cs_ptr, hs_ptr, rs_col, cs_row, total;
     __host__ __device__ LdsLayout(int NS, int LS, int ZS) {
         size_t o = 0;
         auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 15) & ~size_t(15); return at; };
@@ -55,6 +55,7 @@ struct LdsLayout {
         red = take(sizeof(double) * 2 * RED_MAXV * RED_MAXW);
         rs_ptr = take(sizeof(int) * ((size_t)NS + 1));
         cs_ptr = take(sizeof(int) * ((size_t)NS + 1));
+        hs_ptr = take(sizeof(int) * ((size_t)NS + 1));
         rs_col = take(sizeof(uint16_t) * (size_t)ZS);
         cs_row = take(sizeof(uint16_t) * (size_t)ZS);
         total = o;
@@ -118,16 +119,45 @@ constexpr int GCH = 4;   // gathers of one slot issued together before their (or
 template <typename C>
 constexpr int caps_max() { int m = 0; for (int i = 0; i < C::N; i++) m = C::at(i) > m ? C::at(i) : m; return m; }
 
+// dispatch a wave-uniform chunk count nch in [0, MAXCH] to a body instantiated for that count (a straight-line path per
+// count: every LDS gather of the list is issued before the first addition, so the list costs ONE LDS latency, not one per chunk)
+template <int MAXCH, typename F>
+__device__ __forceinline__ void dispatch_chunks(int nch, F &&f) {
+    static_for<MAXCH + 1>([&](auto K) {
+        constexpr int k = decltype(K)::value;
+        if (nch == k) f(K);
+    });
+}
+
 // out[s] = sum_k src[list_s[k]] (k ascending) for every slot s of the thread, through OP(acc, v) which keeps the exact
 // expression of the reference: `acc + v` for E (stored values 1.0) or `acc + s * v` for the scaled transpose.
-// Chunk-major: round c issues the c-th GCH gathers of EVERY slot before any addition, so EPT*GCH independent LDS reads are
-// in flight (the slots are independent sums; inside a slot the additions stay in ascending order).
+// One slot per thread: all gathers of the (wave-uniform) list length first, then the additions in order.
+// Several slots: chunk-major -- round c issues the c-th GCH gathers of EVERY slot before any addition, so EPT*GCH independent
+// LDS reads are in flight (the slots are independent sums; inside a slot the additions stay in ascending order).
 template <typename C, int STRIDE, int COMP, typename OP>
 __device__ __forceinline__ void gather_all(const Lists<C> &g, const uint16_t *idx, OP op, double (&out)[C::N]) {
     constexpr int N = C::N, MAXCAP = caps_max<C>();
     double acc[N];
 #pragma unroll
     for (int s = 0; s < N; s++) acc[s] = 0.0;
+    if constexpr (N == 1) {
+        constexpr int G1 = 2;                                          // granularity of the wave-uniform list length
+        int nch_ = (g.wlen[0] + G1 - 1) / G1;
+#ifdef LPBOX_KO_COLCAP
+        if (STRIDE == 24 && nch_ > LPBOX_KO_COLCAP) nch_ = LPBOX_KO_COLCAP;
+#endif
+#ifdef LPBOX_KO_ROWCAP
+        if (STRIDE == 8 && nch_ > LPBOX_KO_ROWCAP) nch_ = LPBOX_KO_ROWCAP;
+#endif
+        dispatch_chunks<MAXCAP / G1>(nch_, [&](auto K) {
+            constexpr int n = decltype(K)::value * G1;
+            double v[n > 0 ? n : 1];
+#pragma unroll
+            for (int q = 0; q < n; q++) v[q] = lds_ld<COMP>(g.addr[q]);
+#pragma unroll
+            for (int q = 0; q < n; q++) acc[0] = op(acc[0], v[q]);
+        });
+    } else {
     static_for<MAXCAP / GCH>([&](auto CI) {
         constexpr int c = decltype(CI)::value * GCH;
         double v[N][GCH];
@@ -150,6 +180,7 @@ __device__ __forceinline__ void gather_all(const Lists<C> &g, const uint16_t *id
             }
         });
     });
+    }
     static_for<N>([&](auto S) {                                         // long lists: indices from LDS
         constexpr int s = decltype(S)::value;
         for (int k = g.tail_begin[s]; k < g.tail_end[s]; k += GCH) {
@@ -268,7 +299,7 @@ __global__ void __launch_bounds__(T) lp_init_kernel(LpBatchDev bd, const double 
 //   T    threads per instance, EPT variable (and row) slots per thread,
 //   RCAPS / CCAPS  per-slot register capacities (Caps<...>) of the row-task / column gather lists.
 // ------------------------------------------------------------------------------------------------
-template <int T, int EPT, typename RCAPS, typename CCAPS>
+template <int T, int EPT, typename RCAPS, typename CCAPS, typename HCAPS>
 __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_start, int iter_end, int mode) {
     const int l2f = mode & 1, rec = mode & 2;     // rec: keep x after every iteration in xhist (x_iters of the l2f loop; print_fix_info 2/3 of the plain loop)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -286,6 +317,7 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
     double *red = (double *)(smem + L.red);
     int *s_rs_ptr = (int *)(smem + L.rs_ptr);
     int *s_cs_ptr = (int *)(smem + L.cs_ptr);
+    int *s_hs_ptr = (int *)(smem + L.hs_ptr);
     uint16_t *s_rs_col = (uint16_t *)(smem + L.rs_col);
     uint16_t *s_cs_row = (uint16_t *)(smem + L.cs_row);
 
@@ -293,7 +325,8 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
     {
         const int *gp = bd.rs_ptr + (size_t)inst * (bd.NS + 1);
         const int *gc = bd.cs_ptr + (size_t)inst * (bd.NS + 1);
-        for (int i = tid; i <= bd.NS; i += T) { s_rs_ptr[i] = gp[i]; s_cs_ptr[i] = gc[i]; }
+        const int *gh = bd.hs_ptr + (size_t)inst * (bd.NS + 1);
+        for (int i = tid; i <= bd.NS; i += T) { s_rs_ptr[i] = gp[i]; s_cs_ptr[i] = gc[i]; s_hs_ptr[i] = gh[i]; }
         const uint16_t *c0 = bd.rs_col + oz, *r0 = bd.cs_row + oz;
         for (int k = tid; k < nnz; k += T) { s_rs_col[k] = c0[k]; s_cs_row[k] = r0[k]; }
         if (tid == 0) { gx[bd.NS] = 0.0; gl[3 * bd.LS] = 0.0; gl[3 * bd.LS + 1] = 0.0; gl[3 * bd.LS + 2] = 0.0; }   // zero slots
@@ -344,20 +377,27 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
     __syncthreads();   // index sets staged
 
     // ---- gather lists of this thread's rows and columns, kept in registers for the whole launch ----
-    static_assert(RCAPS::N == EPT && CCAPS::N == EPT, "one capacity per slot");
+    static_assert(RCAPS::N == EPT && CCAPS::N == EPT && HCAPS::N == EPT, "one capacity per slot");
     Lists<RCAPS> rl;
-    Lists<CCAPS> cl;
+    Lists<CCAPS> cl;             // the leading entries of this position's own column
+    Lists<HCAPS> hl;             // helper share: a chunk of the tail of the long column of this lane's quad (section 5 of DESIGN.md)
+    bool clong[EPT];             // this lane owns the quad's long column: its sum = own part + the quad's helper partials
+    int anyhelp[EPT];            // wave-uniform: some quad of this wave splits a column
     rl.base = lds_addr(gx); rl.zero = lds_addr(gx + bd.NS);
     cl.base = lds_addr(gl); cl.zero = lds_addr(gl + 3 * bd.LS);
+    hl.base = cl.base; hl.zero = cl.zero;
     int rGmax[EPT];              // wave-uniform largest lane group in the slot
     static_for<EPT>([&](auto S) {
         constexpr int s = decltype(S)::value;
         const int pos = s * T + tid;
         build_list<RCAPS, s, 8>(rl, s_rs_ptr[pos], s_rs_ptr[pos + 1], s_rs_col);
         rGmax[s] = wave_max_int(rG[s]);
-        const int cb = s_cs_ptr[pos], ce = s_cs_ptr[pos + 1];
-        build_list<CCAPS, s, 24>(cl, cb, ce, s_cs_row);
-        Esq[s] = (double)(ce - cb);   // Esq_diag_j = sum of squared entries of column j (LPcpp:2378-2390); entries are 1.0
+        build_list<CCAPS, s, 24>(cl, s_cs_ptr[pos], s_cs_ptr[pos + 1], s_cs_row);
+        build_list<HCAPS, s, 24>(hl, s_hs_ptr[pos], s_hs_ptr[pos + 1], s_cs_row);
+        const int cm = bd.cmeta[on + pos];
+        clong[s] = (cm & 0x8000) != 0;
+        anyhelp[s] = wave_max_int(s_hs_ptr[pos + 1] - s_hs_ptr[pos]) > 0;
+        Esq[s] = (double)(cm & 0x7FFF);   // Esq_diag_j = sum of squared entries of column j (LPcpp:2378-2390); entries are 1.0
     });
     auto op_add = [](double acc, double v) { return acc + v; };                 // res += 1.0 * v
     // out = (E * gx)_row for this thread's row tasks: the G lanes of a task add their interleaved share of the row in
@@ -374,6 +414,49 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
             if (rGmax[s] >= 8) { const double u = v + dpp_mov<0x141>(v); v = rG[s] >= 8 ? u : v; }
             out[s] = v;
         });
+    };
+
+    // out = (E^T * gl[.][COMP])_col for this thread's variables through OP.  A long column is shared inside its quad of lanes:
+    // its owner adds the leading entries, the other lanes of the quad add consecutive chunks of the rest into a second
+    // accumulator after their own (short) columns; the helper partials are combined by an xor butterfly over the quad
+    // ((h0 + h1) + (h2 + h3), the owner's own helper partial is +0.0) and added to the owner's part.  Every partial sum runs
+    // in ascending row order from +0.0.
+    auto quad_sum = [](double v) { v = v + dpp_mov<0xB1>(v); v = v + dpp_mov<0x4E>(v); return v; };
+    auto cols_gather = [&](auto COMPC, auto op, double (&out)[EPT]) {
+        constexpr int COMP = decltype(COMPC)::value;
+        double own[EPT];
+        gather_all<CCAPS, 24, COMP>(cl, s_cs_row, op, own);
+        if constexpr (HCAPS::total > 0) {
+            double hp[EPT];
+            gather_all<HCAPS, 24, COMP>(hl, s_cs_row, op, hp);
+            static_for<EPT>([&](auto S) {
+                constexpr int s = decltype(S)::value;
+                if (anyhelp[s]) { const double ht = quad_sum(hp[s]); out[s] = clong[s] ? own[s] + ht : own[s]; }
+                else out[s] = own[s];
+            });
+        } else {
+#pragma unroll
+            for (int s = 0; s < EPT; s++) out[s] = own[s];
+        }
+    };
+    auto cols_gather2 = [&](auto opa, auto opb, double (&outA)[EPT], double (&outB)[EPT]) {      // components 0 and 1 (rhs assembly)
+        double ownA[EPT], ownB[EPT];
+        gather_all2<CCAPS, 24, 0, 1>(cl, s_cs_row, opa, opb, ownA, ownB);
+        if constexpr (HCAPS::total > 0) {
+            double hA[EPT], hB[EPT];
+            gather_all2<HCAPS, 24, 0, 1>(hl, s_cs_row, opa, opb, hA, hB);
+            static_for<EPT>([&](auto S) {
+                constexpr int s = decltype(S)::value;
+                if (anyhelp[s]) {
+                    const double ta = quad_sum(hA[s]), tb = quad_sum(hB[s]);
+                    outA[s] = clong[s] ? ownA[s] + ta : ownA[s];
+                    outB[s] = clong[s] ? ownB[s] + tb : ownB[s];
+                } else { outA[s] = ownA[s]; outB[s] = ownB[s]; }
+            });
+        } else {
+#pragma unroll
+            for (int s = 0; s < EPT; s++) { outA[s] = ownA[s]; outB[s] = ownB[s]; }
+        }
     };
 
     // ---- early fixing: apply this call's fix vector (LPcpp:1124-1335) as a mask ----
@@ -482,10 +565,14 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
                 r4Et = learning_fact * r4Et;                          // rho4_E_transpose *= learning_fact (:864)
             }
             const double r4 = r4Et;
+#ifdef LPBOX_KO_NOMUL
+            auto op_scaled = [r4](double acc, double v) { return acc + v; };
+#else
             auto op_scaled = [r4](double acc, double v) { return acc + r4 * v; };   // res += (rho4*1.0) * v
+#endif
             // ---------------- rhs (:872-878) and q = E*y1 ----------------
             double rhs[EPT], tAs[EPT], tBs[EPT];
-            gather_all2<CCAPS, 24, 0, 1>(cl, s_cs_row, op_scaled, op_add, tAs, tBs);   // (rho4 E^T)(f - y3) and E^T z4 in one pass
+            cols_gather2(op_scaled, op_add, tAs, tBs);                                  // (rho4 E^T)(f - y3) and E^T z4 in one pass
 #pragma unroll
             for (int s = 0; s < EPT; s++) {
                 const double tA = tAs[s], tB = tBs[s];
@@ -511,7 +598,7 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
             double xt[EPT], r[EPT], p[EPT];
             double p3[3] = {0.0, 0.0, 0.0};
             double tcol[EPT];
-            gather_all<CCAPS, 24, 2>(cl, s_cs_row, op_scaled, tcol);
+            cols_gather(std::integral_constant<int, 2>{}, op_scaled, tcol);
 #pragma unroll
             for (int s = 0; s < EPT; s++) {
                 const double t = tcol[s];
@@ -545,7 +632,11 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
                         STAMP(3)
                         {
                             double q[EPT];
+#ifdef LPBOX_KO_ROWS
+                            for (int s = 0; s < EPT; s++) q[s] = p[s];
+#else
                             rows_gather(q);
+#endif
                             STAMP(4)
 #pragma unroll
                             for (int s = 0; s < EPT; s++) if (rvalid[s]) gl[3 * rgl[s]] = q[s];
@@ -554,7 +645,11 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
                         STAMP(5)
                         double tmp[EPT];
                         double p1[1] = {0.0};
-                        gather_all<CCAPS, 24, 0>(cl, s_cs_row, op_scaled, tcol);
+#ifdef LPBOX_KO_COLS
+                        for (int s = 0; s < EPT; s++) tcol[s] = gl[3 * (tid % 128)];
+#else
+                        cols_gather(std::integral_constant<int, 0>{}, op_scaled, tcol);
+#endif
 #pragma unroll
                         for (int s = 0; s < EPT; s++) {               // tmp = M p (:298), fused p.tmp
                             const double t = tcol[s];
@@ -565,10 +660,16 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
                             p1[0] = p1[0] + (live[s] ? p[s] * tmp[s] : 0.0);
                         }
                         STAMP(6)
+#ifndef LPBOX_KO_RED1
                         block_sum<T, 1>(p1, red, parity);
+#endif
                         STAMP(7)
+#ifdef LPBOX_KO_DIV
+                        const double alpha = absNew * p1[0];
+#else
                         const double alpha = absNew / p1[0];          // :300
                         if (alpha < 0) { pcg_fail = true; break; }    // :301
+#endif
                         double p2[2] = {0.0, 0.0};
                         double z[EPT];
 #pragma unroll
@@ -580,13 +681,23 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
                             p2[1] = p2[1] + (live[s] ? r[s] * z[s] : 0.0);   // :317
                         }
                         STAMP(8)
+#ifndef LPBOX_KO_RED2
                         block_sum<T, 2>(p2, red, parity);
+#endif
                         STAMP(9)
                         residualNorm2 = p2[0];
+#ifdef LPBOX_KO_FIXED_PCG
+                        if (k_it + 1 >= LPBOX_KO_FIXED_PCG) { k_it++; break; }
+#else
                         if (residualNorm2 < threshold) { k_it++; break; }     // :309-312
+#endif
                         const double absOld = absNew;
                         absNew = p2[1];
+#ifdef LPBOX_KO_DIV
+                        const double beta = absNew * absOld;
+#else
                         const double beta = absNew / absOld;          // :318
+#endif
 #pragma unroll
                         for (int s = 0; s < EPT; s++) p[s] = z[s] + beta * p[s];   // :319
                         k_it++;
@@ -747,20 +858,20 @@ size_t lp_window_lds_bytes(int T, int NS, int LS, int ZS) {
 }
 
 // (threads, slots per thread) -> per-slot register capacities of the row-task / column gather lists.
-#define LP_DISPATCH(KERNEL_CALL)                                                                                         \
-    if (T == 256 && EPT == 1) { KERNEL_CALL(256, 1, (Caps<12>), (Caps<24>)) }                                       \
-    else if (T == 256 && EPT == 2) { KERNEL_CALL(256, 2, (Caps<12, 12>), (Caps<24, 8>)) }                                \
-    else if (T == 256 && EPT == 4) { KERNEL_CALL(256, 4, (Caps<12, 12, 12, 12>), (Caps<24, 8, 8, 8>)) }                  \
-    else if (T == 256 && EPT == 8) { KERNEL_CALL(256, 8, (Caps<8, 8, 8, 8, 8, 8, 8, 8>), (Caps<8, 8, 8, 8, 4, 4, 4, 4>)) } \
-    else if (T == 512 && EPT == 1) { KERNEL_CALL(512, 1, (Caps<12>), (Caps<24>)) }                                       \
-    else if (T == 512 && EPT == 2) { KERNEL_CALL(512, 2, (Caps<12, 12>), (Caps<16, 8>)) }                                \
+#define LP_DISPATCH(KERNEL_CALL)                                                                                                          \
+    if (T == 256 && EPT == 1) { KERNEL_CALL(256, 1, (Caps<12>), (Caps<12>), (Caps<8>)) }                                                     \
+    else if (T == 256 && EPT == 2) { KERNEL_CALL(256, 2, (Caps<12, 12>), (Caps<24, 8>), (Caps<0, 0>)) }                                      \
+    else if (T == 256 && EPT == 4) { KERNEL_CALL(256, 4, (Caps<12, 12, 12, 12>), (Caps<24, 8, 8, 8>), (Caps<0, 0, 0, 0>)) }                  \
+    else if (T == 256 && EPT == 8) { KERNEL_CALL(256, 8, (Caps<8, 8, 8, 8, 8, 8, 8, 8>), (Caps<8, 8, 8, 8, 4, 4, 4, 4>), (Caps<0, 0, 0, 0, 0, 0, 0, 0>)) } \
+    else if (T == 512 && EPT == 1) { KERNEL_CALL(512, 1, (Caps<12>), (Caps<12>), (Caps<8>)) }                                                \
+    else if (T == 512 && EPT == 2) { KERNEL_CALL(512, 2, (Caps<12, 12>), (Caps<16, 8>), (Caps<0, 0>)) }                                      \
     else return hipErrorInvalidConfiguration;
 
 #define LP_UNPAREN(...) __VA_ARGS__
 
 hipError_t lp_launch_init(const LpBatchDev &bd, int T, int EPT, const double *f_org, const double *c1_init,
                           const uint8_t *live_init, hipStream_t s) {
-#define CALL_INIT(TT, EE, RR, CCC) hipLaunchKernelGGL((lp_init_kernel<TT, EE>), dim3(bd.B), dim3(TT), 0, s, bd, f_org, c1_init, live_init);
+#define CALL_INIT(TT, EE, RR, CCC, HHH) hipLaunchKernelGGL((lp_init_kernel<TT, EE>), dim3(bd.B), dim3(TT), 0, s, bd, f_org, c1_init, live_init);
     LP_DISPATCH(CALL_INIT)
 #undef CALL_INIT
     return hipGetLastError();
@@ -768,9 +879,9 @@ hipError_t lp_launch_init(const LpBatchDev &bd, int T, int EPT, const double *f_
 
 hipError_t lp_launch_window(const LpBatchDev &bd, int T, int EPT, size_t lds, int iter_start, int iter_end, int l2f,
                             hipStream_t s) {
-#define CALL_WIN(TT, EE, RR, CCC)                                                                              \
+#define CALL_WIN(TT, EE, RR, CCC, HHH)                                                                             \
     {                                                                                                          \
-        auto kfn = lp_window_kernel<TT, EE, LP_UNPAREN RR, LP_UNPAREN CCC>;                                    \
+        auto kfn = lp_window_kernel<TT, EE, LP_UNPAREN RR, LP_UNPAREN CCC, LP_UNPAREN HHH>;                                    \
         hipError_t e = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return e;                                                                         \
         hipLaunchKernelGGL(kfn, dim3(bd.B), dim3(TT), lds, s, bd, iter_start, iter_end, l2f);                  \

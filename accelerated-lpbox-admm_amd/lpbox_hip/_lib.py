@@ -60,6 +60,7 @@ SYMBOLS = {
     "lpbox_get_config": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "lpbox_get_layout": (C.c_int, [C.c_void_p, C.c_int, _ip]),
     "lpbox_get_row_split": (C.c_int, [C.c_void_p, C.c_int, _ip]),
+    "lpbox_get_col_split": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip]),
     "lpbox_get_counters": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "lpbox_get_stop": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "lpbox_kernel_time": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]),

@@ -197,6 +197,13 @@ class LpBatch:
         check(self._L.lpbox_get_row_split(self._h, idx, g), "lpbox_get_row_split")
         return g
 
+    def col_split(self, idx=0):
+        """(own[n], help4[n, 4]): how the kernels associate the sum over each column of E (include/lpbox_hip.h)."""
+        n = self.get_org_n(idx)
+        own, help4 = np.zeros(n, np.int32), np.zeros(4 * n, np.int32)
+        check(self._L.lpbox_get_col_split(self._h, idx, own, help4), "lpbox_get_col_split")
+        return own, help4.reshape(n, 4)
+
     def counters(self, idx=0):
         o, p = C.c_longlong(), C.c_longlong()
         check(self._L.lpbox_get_counters(self._h, idx, C.byref(o), C.byref(p)), "lpbox_get_counters")

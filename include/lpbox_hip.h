@@ -145,6 +145,11 @@ int lpbox_get_layout(lpbox_t *h, int idx, int *pos_of_var);
 /* Number of lanes (1,2,4,8) that share the sum of each row of E in instance idx (lanes_of_row[l]): lane g adds the entries
  * g, g+G, ... of the row in ascending column order, the G partial sums are combined by a butterfly. */
 int lpbox_get_row_split(lpbox_t *h, int idx, int *lanes_of_row);
+/* How the kernels add up column j of E (E^T w) in instance idx: own[j] leading entries (ascending row id) by the variable's
+ * own lane; for a split column the rest in consecutive chunks of help4[4*j + q] entries by lane q = 0..3 of its quad of lanes
+ * (0 for the own lane), the four chunk sums h_q combined as (h0 + h1) + (h2 + h3) and added to the own part.  own[org_n],
+ * help4[4*org_n]; an unsplit column has own[j] = its length and help4 = 0. */
+int lpbox_get_col_split(lpbox_t *h, int idx, int *own, int *help4);
 /* Counters accumulated since init: outer ADMM iterations and PCG iterations of instance idx (LPcpp:894 maxiter). */
 int lpbox_get_counters(lpbox_t *h, int idx, long long *outer_iters, long long *pcg_iters);
 /* Which stop fired in the last call: 0 none, 1 y1_y2, 2 obj_std, 3 PCG alpha<0, 4 all fixed; and iter+1 of the last plain call (LPcpp:1081). */

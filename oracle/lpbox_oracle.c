@@ -176,6 +176,9 @@ struct lpo {
     int gpu_npos;                  /* number of storage positions (>= org_n; holes contribute +0.0) */
     int gpu_chunk;                 /* > 0: two-level order of the large-instance kernels (workgroup partials of `chunk` positions) */
     int *row_G;                    /* GPU order: lanes that share row i of E (1,2,4,8); NULL = 1 */
+    int *col_own, *col_help;       /* GPU order: split of the sum over column j of E (by ORIGINAL variable): own[j] leading entries,
+                                      then chunks of help[4j+q] entries by quad lane q; NULL = unsplit */
+    double *valT; int *curT;       /* scratch of spmv_Et */
     int *orgEr_ptr, *orgEr_col; double *orgEr_val;   /* CSR view of org_E (rows in ascending column order) */
     double *full_v;                /* scratch: a live vector expanded to the original variable order */
     int has_problem, inited;
@@ -194,6 +197,37 @@ static void spmv_orgE_split(lpo_t *o, const double *full_v, double *res) {
         for (int stride = 1; stride < G; stride <<= 1)
             for (int g = 0; g < G; g += 2 * stride) part[g] = part[g] + part[g + stride];
         res[i] = part[0];
+    }
+}
+
+/* Mt * w with Mt = E^T (scaled or not), a vector over the rows of E (LPcpp:102-108 on E_transpose / rho4_E_transpose).
+ * Eigen's column-major product accumulates res[j] over the rows of E in ascending order from 0 -- per j that is the sequential
+ * sum below with no split.  GPU order (lp_window_kernel cols_gather): the own lane adds the first own[j] entries, the rest
+ * goes in consecutive chunks to the lanes q = 0..3 of the variable's quad; res[j] = own + ((h0 + h1) + (h2 + h3)). */
+static void spmv_Et(struct lpo *o, const csc_t *Mt, const double *w, double *res) {
+    if (o->order_mode != LPO_ORDER_GPU || !o->col_own) { spmv(Mt, w, res); return; }
+    const csc_t *E = &o->E;
+    const int n = E->cols;
+    o->valT = (double *)realloc(o->valT, sizeof(double) * (size_t)(E->nnz + 1));
+    o->curT = (int *)realloc(o->curT, sizeof(int) * (size_t)(n + 1));
+    for (int j = 0; j < n; j++) o->curT[j] = E->ptr[j];
+    for (int i = 0; i < Mt->cols; i++)                     /* values of Mt re-ordered like the entries of E (both ascend in i) */
+        for (int k = Mt->ptr[i]; k < Mt->ptr[i + 1]; k++) o->valT[o->curT[Mt->idx[k]]++] = Mt->val[k];
+    for (int j = 0; j < n; j++) {
+        const int oj = o->left_idx[j];
+        const int b = E->ptr[j], e = E->ptr[j + 1];
+        int own = o->col_own[oj];
+        if (own > e - b) own = e - b;
+        double acc = 0.0;
+        int k = b;
+        for (; k < b + own; k++) acc = acc + o->valT[k] * (1.0 * w[E->idx[k]]);
+        if (k < e) {
+            double h[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int q = 0; q < 4; q++)
+                for (int c = 0; c < o->col_help[4 * oj + q] && k < e; c++, k++) h[q] = h[q] + o->valT[k] * (1.0 * w[E->idx[k]]);
+            acc = acc + ((h[0] + h[1]) + (h[2] + h[3]));
+        }
+        res[j] = acc;
     }
 }
 
@@ -235,7 +269,7 @@ void lpo_destroy(lpo_t *o) {
     if (!o) return;
     free_state(o);
     csc_free(&o->E); csc_free(&o->orgE); csc_free(&o->Et); csc_free(&o->r4Et);
-    free(o->b); free(o->f); free(o->gpu_pos); free(o->row_G);
+    free(o->b); free(o->f); free(o->gpu_pos); free(o->row_G); free(o->col_own); free(o->col_help); free(o->valT); free(o->curT);
     free(o->orgEr_ptr); free(o->orgEr_col); free(o->orgEr_val);
     free(o);
 }
@@ -266,6 +300,17 @@ void lpo_set_row_split(lpo_t *o, const int *lanes_of_row, int l) {
     if (lanes_of_row && l > 0) {
         o->row_G = (int *)malloc(sizeof(int) * (size_t)l);
         memcpy(o->row_G, lanes_of_row, sizeof(int) * (size_t)l);
+    }
+}
+
+void lpo_set_col_split(lpo_t *o, const int *own, const int *help4, int n) {
+    free(o->col_own); free(o->col_help);
+    o->col_own = o->col_help = NULL;
+    if (own && help4 && n > 0) {
+        o->col_own = (int *)malloc(sizeof(int) * (size_t)n);
+        o->col_help = (int *)malloc(sizeof(int) * 4 * (size_t)n);
+        memcpy(o->col_own, own, sizeof(int) * (size_t)n);
+        memcpy(o->col_help, help4, sizeof(int) * 4 * (size_t)n);
     }
 }
 
@@ -461,7 +506,7 @@ static void mat_expr_mul(lpo_t *o, const double *x, double *result) {
     double *t1 = o->temp_mm;             /* temp_vec_for_mat_mul: E*x (length l) ... */
     double *t2 = o->temp_mm + l;         /* ... then rho4Et*(.) (length n); Eigen evaluates the aliased product into a temporary */
     spmv_E(o, x, t1);
-    spmv(&o->r4Et, t1, t2);
+    spmv_Et(o, &o->r4Et, t1, t2);
     for (int j = 0; j < n; j++) result[j] += t2[j];
 }
 
@@ -669,9 +714,9 @@ static int admm_iteration(lpo_t *o, int iter, int iter_start, int l2f, int *ret,
         double *fy = o->fy;                   /* (*f_ptr - y3) is evaluated into a temporary vector first */
         double *t = o->temp_mm + l;
         for (int i = 0; i < l; i++) fy[i] = o->f[i] - o->y3[i];
-        spmv(&o->r4Et, fy, t);
+        spmv_Et(o, &o->r4Et, fy, t);
         for (int i = 0; i < n; i++) tv[i] += t[i];
-        spmv(&o->Et, o->z4, t);
+        spmv_Et(o, &o->Et, o->z4, t);
         for (int i = 0; i < n; i++) tv[i] -= t[i];
     }
 

@@ -45,6 +45,8 @@ void lpo_set_order(lpo_t *o, int mode, int T);
 void lpo_set_positions(lpo_t *o, const int *pos_of_var, int n, int npos);
 /* GPU order only: lanes_of_row[i] in {1,2,4,8} lanes share the sum of row i of E (lpbox_get_row_split). */
 void lpo_set_row_split(lpo_t *o, const int *lanes_of_row, int l);
+/* GPU order of the column sums (E^T w): own[n] leading entries by the own lane, help4[4n] chunk sizes by quad lane (include/lpbox_hip.h lpbox_get_col_split) */
+void lpo_set_col_split(lpo_t *o, const int *own, const int *help4, int n);
 /* GPU order of the LARGE-instance kernels: reductions are two-level (a block tree over every `chunk` consecutive positions, then
  * the same tree over the chunk partials).  0 = single workgroup (default). */
 void lpo_set_chunk(lpo_t *o, int chunk);

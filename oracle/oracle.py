@@ -45,6 +45,7 @@ def lib():
     L.lpo_set_chunk.argtypes = [C.c_void_p, C.c_int]
     L.lpo_set_positions.argtypes = [C.c_void_p, _ip, C.c_int, C.c_int]
     L.lpo_set_row_split.argtypes = [C.c_void_p, _ip, C.c_int]
+    L.lpo_set_col_split.argtypes = [C.c_void_p, _ip, _ip, C.c_int]
     L.lpo_set_problem.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _ip, _ip, C.c_void_p, _dp, _dp]
     L.lpo_read_files.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int]
     L.lpo_init.argtypes = [C.c_void_p]
@@ -78,7 +79,7 @@ def lib():
 class LpOracle:
     """Mirror of the reference's PyLPboxADMMsolver (lpbox.pyx:7-76) on the CPU oracle."""
 
-    def __init__(self, print_info=0, order=ORDER_EIGEN, T=512, verbose=False, positions=None, npos=0, row_split=None, chunk=0):
+    def __init__(self, print_info=0, order=ORDER_EIGEN, T=512, verbose=False, positions=None, npos=0, row_split=None, chunk=0, col_split=None):
         self.L = lib()
         self.h = C.c_void_p(self.L.lpo_create(int(print_info)))
         self.L.lpo_set_order(self.h, order, T)
@@ -91,6 +92,10 @@ class LpOracle:
         if row_split is not None:
             row_split = np.ascontiguousarray(row_split, np.int32)
             self.L.lpo_set_row_split(self.h, row_split, len(row_split))
+        if col_split is not None:
+            own = np.ascontiguousarray(col_split[0], np.int32)
+            help4 = np.ascontiguousarray(col_split[1], np.int32).ravel()
+            self.L.lpo_set_col_split(self.h, own, help4, len(own))
 
     def __del__(self):
         try:

@@ -10,7 +10,7 @@ type `valid_seed` used in `__main__`; an empty stand-in module satisfies that im
 
 Outputs (data only -- inputs of the solver; no reference source text is stored):
   lp_100_500_seed0.npz        first 256 instances j=100 items / k=500 bids   (BASELINE configs[0], [1])
-  lp_500_2000_seed0.npz       first 4 instances   j=500 / k=2000             (configs[3] shape)
+  lp_500_2000_seed0.npz       first 256 instances j=500 / k=2000             (BASELINE configs[3]: one GPU's share of the 2048)
   lp_20_60_seed0.npz          first 8 tiny instances j=20 / k=60             (fast parity cases)
   instance/100_500/instance_{1,2}_{C,b}.txt   the generator's own text files (reader tests)
 
@@ -85,12 +85,15 @@ def make_batch(gi, n_items, n_bids, count, seed, keep_text=0, text_dir=None):
 
 def main():
     gi = load_generator()
+    only = sys.argv[1:]
     jobs = [
         ("lp_20_60_seed0.npz", 20, 60, 8, 0, None),
         ("lp_100_500_seed0.npz", 100, 500, 256, 2, os.path.join(HERE, "instance", "100_500")),
-        ("lp_500_2000_seed0.npz", 500, 2000, 4, 0, None),
+        ("lp_500_2000_seed0.npz", 500, 2000, 256, 0, None),
     ]
     for name, j, k, count, keep, tdir in jobs:
+        if only and name not in only:
+            continue
         d = make_batch(gi, j, k, count, 0, keep, tdir)
         np.savez_compressed(os.path.join(HERE, name), **d)
         print(name, "instances", count, "n", d["n"][:4], "l", d["l"][:4], "nnz", d["nnz"][:4])

@@ -12,8 +12,8 @@ def lp_instances(name):
     return O.load_lp_batch(os.path.join(GOLDEN, name))
 
 
-def make_oracle(I, order=O.ORDER_EIGEN, T=512, positions=None, npos=0, row_split=None):
-    s = O.LpOracle(0, order=order, T=T, positions=positions, npos=npos, row_split=row_split)
+def make_oracle(I, order=O.ORDER_EIGEN, T=512, positions=None, npos=0, row_split=None, col_split=None):
+    s = O.LpOracle(0, order=order, T=T, positions=positions, npos=npos, row_split=row_split, col_split=col_split)
     s.set_problem(I["n"], I["l"], I["colptr"], I["rowidx"], I["b"], I.get("f"))
     s.solve_init()
     return s
@@ -44,7 +44,7 @@ def oracle_like(g, I):
 def oracle_for(batch, idx, I):
     cfg = batch.config()
     return make_oracle(I, O.ORDER_GPU, cfg["threads"], batch.layout(idx), cfg["threads"] * cfg["elems_per_thread"],
-                       batch.row_split(idx))
+                       batch.row_split(idx), batch.col_split(idx))
 
 
 # ------------------------------------------------------------------------------------------------

@@ -29,7 +29,7 @@ def test_lp_test_py_sequence(tmp_path, monkeypatch):
         # the oracle on the same files, in this solver's reduction order
         cfg = solver.batch.config()
         o = O.LpOracle(0, order=O.ORDER_GPU, T=cfg["threads"], positions=solver.batch.layout(0),
-                       npos=cfg["threads"] * cfg["elems_per_thread"], row_split=solver.batch.row_split(0))
+                       npos=cfg["threads"] * cfg["elems_per_thread"], row_split=solver.batch.row_split(0), col_split=solver.batch.col_split(0))
         o.read_files(f"../cython_solver/data/instance/100_500/instance_{i}_C.txt", f"../cython_solver/data/instance/100_500/instance_{i}_b.txt", 100)
         o.solve_init()
         o.solve_iter(0, int(1e4))

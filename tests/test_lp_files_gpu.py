@@ -54,7 +54,7 @@ def test_xiters_csv_and_allres(tmp_path):
     # first row = x after the first iteration: the oracle in the same reduction order agrees to the printed digits
     cfg = s.batch.config()
     o = O.LpOracle(0, order=O.ORDER_GPU, T=cfg["threads"], positions=s.batch.layout(0),
-                   npos=cfg["threads"] * cfg["elems_per_thread"], row_split=s.batch.row_split(0))
+                   npos=cfg["threads"] * cfg["elems_per_thread"], row_split=s.batch.row_split(0), col_split=s.batch.col_split(0))
     o.read_files(os.path.join(root, "instance/100_500/instance_1_C.txt"), os.path.join(root, "instance/100_500/instance_1_b.txt"), 100)
     o.solve_init()
     o.solve_iter(0, 1)
