@@ -95,6 +95,9 @@ def main():
         if only and name not in only:
             continue
         d = make_batch(gi, j, k, count, 0, keep, tdir)
+        if count > 64:                                 # large batches: row indices as uint16 (loaders widen them again)
+            assert d["rowidx"].max() < 65536
+            d["rowidx"] = d["rowidx"].astype(np.uint16)
         np.savez_compressed(os.path.join(HERE, name), **d)
         print(name, "instances", count, "n", d["n"][:4], "l", d["l"][:4], "nnz", d["nnz"][:4])
 
