@@ -70,3 +70,4 @@ hipError_t big_launch_pcg_upd(const BigDev &d, int *parity, hipStream_t s);
 hipError_t big_launch_post(const BigDev &d, int *parity, hipStream_t s);              // duals z1,z2, partials(5), gsrc = x
 hipError_t big_launch_z4(const BigDev &d, int init_only, int *parity, hipStream_t s); // Ex = q [, z4 update]
 hipError_t big_launch_resume(const BigDev &d, int reset_pcg_max, int *parity, hipStream_t s);
+hipError_t big_launch_rank_sum(const double *g, int W, long count, long stride, double *out, hipStream_t s);   // rank-ordered sum of W gathered contributions

@@ -6,6 +6,9 @@
 #include "lpbox_big.h"
 #include "lpbox_capi_internal.h"
 
+#include <rccl/rccl.h>     // types only: the library is dlopen'ed (no link dependency; a process that has torch loaded shares torch's copy)
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -24,6 +27,40 @@ struct Buf {
     hipError_t alloc(size_t c) { release(); count = c; return c ? hipMalloc((void **)&p, c * sizeof(Tp)) : hipSuccess; }
     void release() { if (p) (void)hipFree(p); p = nullptr; count = 0; }
 };
+// RCCL entry points, resolved at run time
+struct RcclApi {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi g_rccl;
+
+int rccl_load() {
+    if (g_rccl.lib) return LPBOX_OK;
+    const char *names[] = {getenv("LPBOX_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"};
+    void *lib = nullptr;
+    for (const char *nm : names) if (nm && *nm && (lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!lib) return lpbox_fail(LPBOX_E_STATE, "cannot load librccl.so: %s", dlerror());
+#define RSYM(field, name) do { *(void **)&g_rccl.field = dlsym(lib, name); if (!g_rccl.field) return lpbox_fail(LPBOX_E_STATE, "librccl.so lacks %s", name); } while (0)
+    RSYM(GetUniqueId, "ncclGetUniqueId"); RSYM(CommInitRank, "ncclCommInitRank"); RSYM(CommDestroy, "ncclCommDestroy");
+    RSYM(AllGather, "ncclAllGather"); RSYM(Send, "ncclSend"); RSYM(Recv, "ncclRecv");
+    RSYM(GroupStart, "ncclGroupStart"); RSYM(GroupEnd, "ncclGroupEnd"); RSYM(GetErrorString, "ncclGetErrorString");
+#undef RSYM
+    g_rccl.lib = lib;
+    return LPBOX_OK;
+}
+#define NCCLCHK(expr)                                                                                                      \
+    do {                                                                                                                   \
+        ncclResult_t r_ = (expr);                                                                                          \
+        if (r_ != ncclSuccess) return lpbox_fail(LPBOX_E_HIP, "%s failed: %s", #expr, g_rccl.GetErrorString(r_));          \
+    } while (0)
 }  // namespace
 
 struct lpbox_big {
@@ -34,12 +71,14 @@ struct lpbox_big {
     bool has_problem = false, uploaded = false, inited = false, own_stream = false;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    lpbox_allreduce_fn ar = nullptr; void *ar_user = nullptr;
+    lpbox_allgather_fn ag = nullptr; void *ag_user = nullptr;   // exchange through the caller (tests: gloo) ...
+    ncclComm_t comm = nullptr;                                  // ... or through RCCL, driven from here (no Python in the loop)
+    long q_cap = 0;                                             // doubles allocated behind q (l rounded up to a multiple of world)
     int G = 0, Gl = 0, EPT = 2, EPTl = 2, kmax = 28, parity = 0;
     bool adaptive = true;
     double kernel_ms = 0.0; long long launches = 0, collectives = 0;
     Buf<int> d_rptr, d_rcol, d_cptr, d_crow;
-    Buf<double> x, y1, y2, z1, z2, db, pd, dinv, rhs, r, z, tmp, p0, p1, gsrc, y3, z4, df, fy, Ex, q, part, red, xt, xhist, xi_out;
+    Buf<double> x, y1, y2, z1, z2, db, pd, dinv, rhs, r, z, tmp, p0, p1, gsrc, y3, z4, df, fy, Ex, q, part, red, xt, xhist, xi_out, gath, flag;
     Buf<uint8_t> live, newfix;
     Buf<double2> zp;
     Buf<int> d_live_idx;
@@ -47,7 +86,6 @@ struct lpbox_big {
     long n_live_glob = 0;                 // live variables over all ranks
     int ws_cap = 0, xi_rows = 0;
     bool xi_valid = false;
-    double *ext_q = nullptr, *ext_red = nullptr;     // caller-owned exchange buffers (e.g. torch tensors), optional
     Buf<BigState> st;
     BigState hst;
 
@@ -58,7 +96,7 @@ struct lpbox_big {
         d.x = x.p; d.y1 = y1.p; d.y2 = y2.p; d.z1 = z1.p; d.z2 = z2.p; d.b = db.p; d.pd = pd.p; d.dinv = dinv.p; d.rhs = rhs.p;
         d.r = r.p; d.z = z.p; d.tmp = tmp.p; d.p0 = p0.p; d.p1 = p1.p; d.gsrc = gsrc.p;
         d.zp = zp.p; d.xt = xt.p; d.live = live.p; d.newfix = newfix.p; d.xhist = xhist.p; d.ws_cap = ws_cap;
-        d.y3 = y3.p; d.z4 = z4.p; d.f = df.p; d.fy = fy.p; d.Ex = Ex.p; d.q = ext_q ? ext_q : q.p; d.part = part.p; d.red = ext_red ? ext_red : red.p; d.st = st.p;
+        d.y3 = y3.p; d.z4 = z4.p; d.f = df.p; d.fy = fy.p; d.Ex = Ex.p; d.q = q.p; d.part = part.p; d.red = red.p; d.st = st.p;
         return d;
     }
 };
@@ -72,13 +110,53 @@ int use_device(lpbox_big *h) {
     return LPBOX_OK;
 }
 
+// In-place sum of `count` doubles at ptr over all ranks with a FIXED association: element i = ((c0[i] + c1[i]) + c2[i]) + ...
+// in rank order, whatever the transport -- so a W-rank run is reproducible and comparable bit for bit with the oracle's model of
+// the rank partition (oracle/lpbox_oracle.c lpo_set_ranks).  Transport: RCCL driven from here (vectors: exchange of row blocks
+// = reduce-scatter with our own adds, then an all-gather of the reduced blocks; scalars: one all-gather), or the caller's
+// all-gather callback (tests: gloo).  One rank without a transport: nothing to do.
 int allreduce(lpbox_big *h, double *ptr, long count) {
-    if (h->world <= 1) return LPBOX_OK;
-    if (!h->ar) return lpbox_fail(LPBOX_E_STATE, "world = %d but no all-reduce callback was set", h->world);
+    if (!h->comm && !h->ag) {
+        if (h->world > 1) return lpbox_fail(LPBOX_E_STATE, "world = %d but neither an RCCL communicator nor an all-gather callback was set", h->world);
+        return LPBOX_OK;
+    }
+    const int W = h->world;
+    if (h->comm && count > 64) {
+        const long lb = (count + W - 1) / W;                        // row block per rank (ptr has room for W * lb doubles)
+        if ((long)W * lb > h->q_cap || ptr != h->q.p) return lpbox_fail(LPBOX_E_STATE, "vector exchange outside the padded buffer");
+        NCCLCHK(g_rccl.GroupStart());
+        for (int pr = 0; pr < W; pr++) {
+            NCCLCHK(g_rccl.Send(ptr + (long)pr * lb, (size_t)lb, ncclDouble, pr, h->comm, h->stream));
+            NCCLCHK(g_rccl.Recv(h->gath.p + (long)pr * lb, (size_t)lb, ncclDouble, pr, h->comm, h->stream));
+        }
+        NCCLCHK(g_rccl.GroupEnd());
+        HIPCHK(big_launch_rank_sum(h->gath.p, W, lb, lb, ptr + (long)h->rank * lb, h->stream));
+        NCCLCHK(g_rccl.AllGather(ptr + (long)h->rank * lb, ptr, (size_t)lb, ncclDouble, h->comm, h->stream));
+        h->collectives += 2;
+        return LPBOX_OK;
+    }
+    if (h->comm) NCCLCHK(g_rccl.AllGather(ptr, h->gath.p, (size_t)count, ncclDouble, h->comm, h->stream));
+    else {
+        const int rc = h->ag(ptr, count, h->gath.p, h->ag_user);
+        if (rc != 0) return lpbox_fail(LPBOX_E_HIP, "all-gather callback failed (%d)", rc);
+    }
+    HIPCHK(big_launch_rank_sum(h->gath.p, W, count, count, ptr, h->stream));
     h->collectives++;
-    const int rc = h->ar(ptr, count, h->ar_user);
-    if (rc != 0) return lpbox_fail(LPBOX_E_HIP, "all-reduce callback failed (%d)", rc);
     return LPBOX_OK;
+}
+
+// every rank learns whether ANY rank wants to bail out, before a state-changing collective is entered (a rank that returned early
+// on its own would leave the others waiting inside the next exchange)
+int agree_ok(lpbox_big *h, bool ok_here) {
+    if (!h->comm && !h->ag) return ok_here ? LPBOX_OK : -1;
+    const double v = ok_here ? 0.0 : 1.0;
+    HIPCHK(hipMemcpyAsync(h->flag.p, &v, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    int rc = allreduce(h, h->flag.p, 1);
+    if (rc < 0) return rc;
+    double tot = 0.0;
+    HIPCHK(hipMemcpyAsync(&tot, h->flag.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return tot == 0.0 ? LPBOX_OK : -1;
 }
 
 #define CHK(expr) do { int rc_ = (expr); if (rc_ < 0) return rc_; } while (0)
@@ -141,8 +219,9 @@ void lpbox_big_destroy(lpbox_big_t *h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->d_rptr.release(); h->d_rcol.release(); h->d_cptr.release(); h->d_crow.release();
     for (Buf<double> *bp : {&h->x, &h->y1, &h->y2, &h->z1, &h->z2, &h->db, &h->pd, &h->dinv, &h->rhs, &h->r, &h->z, &h->tmp, &h->p0, &h->p1,
-                            &h->gsrc, &h->y3, &h->z4, &h->df, &h->fy, &h->Ex, &h->q, &h->part, &h->red, &h->xt, &h->xhist, &h->xi_out})
+                            &h->gsrc, &h->y3, &h->z4, &h->df, &h->fy, &h->Ex, &h->q, &h->part, &h->red, &h->xt, &h->xhist, &h->xi_out, &h->gath, &h->flag})
         bp->release();
+    if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(h->comm);
     h->st.release(); h->live.release(); h->newfix.release(); h->d_live_idx.release(); h->zp.release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -157,16 +236,33 @@ int lpbox_big_set_stream(lpbox_big_t *h, void *hip_stream) {
     return LPBOX_OK;
 }
 
-int lpbox_big_set_exchange(lpbox_big_t *h, void *q_dev, void *red_dev) {
+int lpbox_big_set_allgather(lpbox_big_t *h, lpbox_allgather_fn fn, void *user) {
     if (!h) return lpbox_fail(LPBOX_E_BADHANDLE, "bad handle");
-    if (h->inited) return lpbox_fail(LPBOX_E_STATE, "exchange buffers must be set before solve_init");
-    h->ext_q = (double *)q_dev; h->ext_red = (double *)red_dev;
+    h->ag = fn; h->ag_user = user;
     return LPBOX_OK;
 }
 
-int lpbox_big_set_allreduce(lpbox_big_t *h, lpbox_allreduce_fn fn, void *user) {
-    if (!h) return lpbox_fail(LPBOX_E_BADHANDLE, "bad handle");
-    h->ar = fn; h->ar_user = user;
+int lpbox_big_rccl_unique_id(void *out128) {
+    if (!out128) return lpbox_fail(LPBOX_E_BADARG, "null output");
+    int rc = rccl_load();
+    if (rc < 0) return rc;
+    ncclUniqueId id;
+    NCCLCHK(g_rccl.GetUniqueId(&id));
+    memcpy(out128, &id, sizeof(id));
+    return (int)sizeof(id);
+}
+
+int lpbox_big_rccl_init(lpbox_big_t *h, const void *unique_id128) {
+    if (!h || !unique_id128) return lpbox_fail(LPBOX_E_BADHANDLE, "bad handle / id");
+    if (h->comm) return lpbox_fail(LPBOX_E_STATE, "communicator already created");
+    if (h->inited) return lpbox_fail(LPBOX_E_STATE, "the communicator must be created before solve_init");
+    int rc = rccl_load();
+    if (rc < 0) return rc;
+    rc = use_device(h);
+    if (rc < 0) return rc;
+    ncclUniqueId id;
+    memcpy(&id, unique_id128, sizeof(id));
+    NCCLCHK(g_rccl.CommInitRank(&h->comm, h->world, id, h->rank));
     return LPBOX_OK;
 }
 
@@ -214,7 +310,12 @@ int lpbox_big_init(lpbox_big_t *h) {
             HIPCHK(bp->alloc(n));
         HIPCHK(h->live.alloc(n)); HIPCHK(h->newfix.alloc(n)); HIPCHK(h->d_live_idx.alloc(n)); HIPCHK(h->zp.alloc(n));
         HIPCHK(hipMemset(h->newfix.p, 0, (size_t)n));
-        for (Buf<double> *bp : {&h->y3, &h->z4, &h->df, &h->fy, &h->Ex, &h->q}) HIPCHK(bp->alloc(l));
+        for (Buf<double> *bp : {&h->y3, &h->z4, &h->df, &h->fy, &h->Ex}) HIPCHK(bp->alloc(l));
+        h->q_cap = (long)h->world * (((long)l + h->world - 1) / h->world);           // whole row blocks for the exchange
+        HIPCHK(h->q.alloc((size_t)h->q_cap)); HIPCHK(hipMemset(h->q.p, 0, sizeof(double) * (size_t)h->q_cap));
+        if (h->comm) HIPCHK(h->gath.alloc((size_t)std::max<long>(h->q_cap, 64L * h->world)));          // W row blocks, or W scalar groups
+        else if (h->ag) HIPCHK(h->gath.alloc((size_t)h->world * (size_t)std::max(l, 64)));              // W whole contributions
+        HIPCHK(h->flag.alloc(8));
         HIPCHK(h->part.alloc((size_t)BIG_NPART * h->G)); HIPCHK(h->red.alloc(BIG_NPART)); HIPCHK(h->st.alloc(2));
         HIPCHK(hipMemcpy(h->d_rptr.p, h->rptr.data(), sizeof(int) * ((size_t)l + 1), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d_rcol.p, h->rcol.data(), sizeof(int) * (size_t)h->nnz, hipMemcpyHostToDevice));
@@ -291,19 +392,25 @@ int lpbox_big_iterate_l2f(lpbox_big_t *h, int iter_start, int iter_end, const do
     CHK(use_device(h));
     const int n_live_loc = (int)h->left_idx.size();
     std::vector<uint8_t> nf;
+    std::vector<int> keep;
+    bool ok = true;
     if (num_global != 0) {
-        if (!vec_local && n_live_loc) return lpbox_fail(LPBOX_E_BADARG, "fix vector missing");
-        nf.assign(h->n_loc, 0);
-        std::vector<int> keep; keep.reserve(n_live_loc);
-        long cnt = 0;
-        for (int q = 0; q < n_live_loc; q++) {
-            const int j = h->left_idx[q];
-            if (vec_local[q] == 1) { nf[j] = 2; cnt++; } else if (vec_local[q] == 0) { nf[j] = 1; cnt++; } else keep.push_back(j);
+        if (!vec_local && n_live_loc) { lpbox_fail(LPBOX_E_BADARG, "fix vector missing"); ok = false; }
+        else {
+            nf.assign(h->n_loc, 0);
+            keep.reserve(n_live_loc);
+            long cnt = 0;
+            for (int q = 0; q < n_live_loc; q++) {
+                const int j = h->left_idx[q];
+                if (vec_local[q] == 1) { nf[j] = 2; cnt++; } else if (vec_local[q] == 0) { nf[j] = 1; cnt++; } else keep.push_back(j);
+            }
+            if (h->world == 1 && cnt != num_global) { lpbox_fail(LPBOX_E_BADARG, "vec fixes %ld variables but num = %ld", cnt, num_global); ok = false; }
+            else if (cnt > num_global) { lpbox_fail(LPBOX_E_BADARG, "this rank fixes %ld variables, more than the global count %ld", cnt, num_global); ok = false; }
         }
-        if (h->world == 1 && cnt != num_global) return lpbox_fail(LPBOX_E_BADARG, "vec fixes %ld variables but num = %ld", cnt, num_global);
-        if (cnt > num_global) return lpbox_fail(LPBOX_E_BADARG, "this rank fixes %ld variables, more than the global count %ld", cnt, num_global);
-        h->left_idx.swap(keep);
     }
+    // all ranks fail together: nobody enters the state-changing collectives below unless everybody passed validation
+    if (agree_ok(h, ok) != LPBOX_OK) return ok ? lpbox_fail(LPBOX_E_BADARG, "another rank rejected its arguments of this call") : LPBOX_E_BADARG;
+    if (num_global != 0) h->left_idx.swap(keep);
     if (ws > 0 && (h->ws_cap < ws || !h->xhist.p)) {
         HIPCHK(hipStreamSynchronize(h->stream));
         HIPCHK(h->xhist.alloc((size_t)ws * h->n_loc));
@@ -328,7 +435,7 @@ int lpbox_big_iterate_l2f(lpbox_big_t *h, int iter_start, int iter_end, const do
         h->n_live_glob = n_live_new;
     }
     h->xi_left = h->left_idx; h->xi_rows = (int)h->left_idx.size();
-    if (ws > 0) HIPCHK(hipMemsetAsync(h->xhist.p, 0, sizeof(double) * (size_t)ws * h->n_loc, h->stream));   // x_iters = Zero (:1113)
+    if (h->ws_cap > 0) HIPCHK(hipMemsetAsync(h->xhist.p, 0, sizeof(double) * (size_t)h->ws_cap * h->n_loc, h->stream));   // x_iters = Zero (:1113): ALL staged columns, also those of an earlier, longer window
     if (h->xi_rows) HIPCHK(hipMemcpyAsync(h->d_live_idx.p, h->xi_left.data(), sizeof(int) * (size_t)h->xi_rows, hipMemcpyHostToDevice, h->stream));
     CHK(run_window(h, d, iter_end));        // synchronises: nf / xi_left stay alive until here
     h->xi_valid = true;

@@ -567,6 +567,16 @@ __global__ void __launch_bounds__(T) big_k_fix3(BigDev d, int in, int out, long 
 }
 
 // out[r*ws + c] = x after iteration c of the r-th LOCAL live variable (get_x_iters_d, LPcpp:1616-1627)
+// out[i] = g[0][i] + g[1][i] + ... + g[W-1][i], added in RANK ORDER: the cross-rank association of every sum over variables of the
+// variable-sharded run (each g[r] is the contribution of rank r; every rank runs this on the same gathered data and gets the same bits).
+__global__ void big_k_rank_sum(const double *g, int W, long count, long stride, double *out) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+        double acc = g[i];
+        for (int r = 1; r < W; r++) acc = acc + g[(long)r * stride + i];
+        out[i] = acc;
+    }
+}
+
 __global__ void big_k_pack_xiters(BigDev d, const int *live_idx, int rows, int ws, double *out) {
     const long total = (long)rows * ws;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
@@ -604,6 +614,12 @@ hipError_t big_launch_pack_xiters(const BigDev &d, const int *live_idx, int rows
     const long total = (long)rows * ws;
     const int grid = (int)std::min<long>((total + 255) / 256, 65535);
     hipLaunchKernelGGL(big_k_pack_xiters, dim3(grid), dim3(256), 0, s, d, live_idx, rows, ws, out);
+    return hipGetLastError();
+}
+hipError_t big_launch_rank_sum(const double *g, int W, long count, long stride, double *out, hipStream_t s) {
+    if (count <= 0) return hipSuccess;
+    const int grid = (int)std::min<long>((count + 255) / 256, 4096);
+    hipLaunchKernelGGL(big_k_rank_sum, dim3(grid), dim3(256), 0, s, g, W, count, stride, out);
     return hipGetLastError();
 }
 hipError_t big_launch_set_window(const BigDev &d, int iter_start, int iter_end, int l2f, int *parity, hipStream_t s) {

@@ -69,8 +69,9 @@ SYMBOLS = {
     "lpbox_big_create": (C.c_void_p, [C.c_int, C.c_int, C.c_int]),
     "lpbox_big_destroy": (None, [C.c_void_p]),
     "lpbox_big_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
-    "lpbox_big_set_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
-    "lpbox_big_set_exchange": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lpbox_big_set_allgather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lpbox_big_rccl_unique_id": (C.c_int, [C.c_void_p]),
+    "lpbox_big_rccl_init": (C.c_int, [C.c_void_p, C.c_void_p]),
     "lpbox_big_set_problem": (C.c_int, [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, _ip, _ip, _dp, C.c_void_p]),
     "lpbox_big_init": (C.c_int, [C.c_void_p]),
     "lpbox_big_iterate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]),
@@ -93,7 +94,7 @@ SYMBOLS = {
     "lpbox_bqp_get_scalar": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]),
 }
 
-ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_long, C.c_void_p)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p)
 
 _lib = None
 

@@ -1,9 +1,17 @@
-"""One large LP, variable-sharded over the ranks of a torch.distributed process group (BASELINE config 5).
+"""One large LP, variable-sharded over the ranks of a process group (BASELINE config 5).
 
-Every rank holds a contiguous block of columns of E and runs the large-instance kernels of liblpbox_hip.so on its GPU; the
-library calls back into `BigLp._allreduce` wherever the algorithm sums over all variables (E*v: an l-vector per PCG
-iteration; a handful of scalars per reduction), which is a `torch.distributed.all_reduce` (backend "nccl" = RCCL over xGMI;
-"gloo" through host staging for tests).  With world == 1 no collective is issued and torch is not needed.
+Every rank holds a contiguous block of columns of E and runs the large-instance kernels of liblpbox_hip.so on its GPU.  Where the
+algorithm sums over all variables (E*v: an l-vector per PCG iteration; a handful of scalars per reduction) the ranks exchange their
+contributions and every rank adds them in rank order (reproducible; exact CPU model in the oracle).  Transport:
+
+* `transport="rccl"` (default when torch.distributed runs on "nccl"): the LIBRARY drives RCCL itself on its stream -- grouped
+  send/recv of row blocks + one all-gather per E*v, one all-gather per scalar group; Python only hands the 128-byte communicator id
+  from rank 0 to the others once (control plane).
+* `transport="callback"` (default on "gloo", used by the tests on the one-GPU box): the library calls back into `_allgather`, a
+  `torch.distributed.all_gather` through host staging.
+
+With world == 1 no collective is issued and torch is not needed (transport="rccl" with world == 1 builds a one-rank communicator
+and runs the whole exchange path against itself: a test of that path on a single GPU).
 """
 import ctypes as C
 
@@ -14,8 +22,17 @@ from ._lib import check
 from .dist import shard_range
 
 
+def _dev_tensor(ptr, count):
+    """Zero-copy torch view of `count` doubles of device memory owned by the library."""
+    import torch
+
+    class _Dev:
+        __cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+    return torch.as_tensor(_Dev(), device="cuda")
+
+
 class BigLp:
-    def __init__(self, problem, rank=0, world=1, device=0, use_torch_stream=None):
+    def __init__(self, problem, rank=0, world=1, device=0, use_torch_stream=None, transport=None):
         """problem: dict(n, l, colptr, rowidx, b[, f]) of the WHOLE instance (CSC, 0/1 pattern, b already negated)."""
         self._L = _lib.load()
         self.rank, self.world = int(rank), int(world)
@@ -32,38 +49,58 @@ class BigLp:
         if not h:
             check(-2, "lpbox_big_create")
         self._h = C.c_void_p(h)
-        self._keep = []
-        if world > 1 or use_torch_stream:
+        if transport is None and world > 1:
+            import torch.distributed as dist
+            transport = "rccl" if dist.get_backend() == "nccl" else "callback"
+        self.transport = transport
+        self._stream = None
+        if world > 1 or use_torch_stream or transport:
             import torch
             torch.cuda.set_device(device)
-            self._q = torch.zeros(l, dtype=torch.float64, device="cuda")
-            self._red = torch.zeros(8, dtype=torch.float64, device="cuda")
-            check(self._L.lpbox_big_set_stream(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "lpbox_big_set_stream")
-            check(self._L.lpbox_big_set_exchange(self._h, C.c_void_p(self._q.data_ptr()), C.c_void_p(self._red.data_ptr())),
-                  "lpbox_big_set_exchange")
-            if world > 1:
-                self._cb = _lib.ALLREDUCE_FN(self._allreduce)
-                check(self._L.lpbox_big_set_allreduce(self._h, C.cast(self._cb, C.c_void_p), None), "lpbox_big_set_allreduce")
+            self._stream = torch.cuda.current_stream()
+            check(self._L.lpbox_big_set_stream(self._h, C.c_void_p(self._stream.cuda_stream)), "lpbox_big_set_stream")
+        if transport == "rccl":
+            uid = (C.c_ubyte * 128)()
+            if self.rank == 0:
+                check(self._L.lpbox_big_rccl_unique_id(uid), "lpbox_big_rccl_unique_id")
+            if world > 1:                                    # control plane: the id travels once, through whatever group exists
+                import torch
+                import torch.distributed as dist
+                t = torch.tensor(list(bytes(uid)), dtype=torch.uint8, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+                dist.broadcast(t, 0)
+                uid = (C.c_ubyte * 128)(*t.cpu().tolist())
+            check(self._L.lpbox_big_rccl_init(self._h, uid), "lpbox_big_rccl_init")
+        elif transport == "callback":
+            self._cb = _lib.ALLGATHER_FN(self._allgather)
+            check(self._L.lpbox_big_set_allgather(self._h, C.cast(self._cb, C.c_void_p), None), "lpbox_big_set_allgather")
+        elif world > 1:
+            raise ValueError(f"unknown transport {transport!r}")
         fp = None
         if f is not None:
             f = np.ascontiguousarray(f, np.float64)
             fp = f.ctypes.data_as(C.c_void_p)
         check(self._L.lpbox_big_set_problem(self._h, n, self.c0, self.c1 - self.c0, l, colptr, rowidx, b, fp), "lpbox_big_set_problem")
 
-    def _allreduce(self, ptr, count, user):
+    def _allgather(self, send_ptr, count, recv_ptr, user):
+        """recv[r*count:(r+1)*count] := rank r's send[0:count], ordered on the library's stream."""
         try:
+            import torch
             import torch.distributed as dist
-            t = self._q if ptr == self._q.data_ptr() else self._red
-            v = t[:count]
-            if dist.get_backend() == "nccl":
-                dist.all_reduce(v)
-            else:                       # gloo (tests): stage through the host
-                c = v.cpu()
-                dist.all_reduce(c)
-                v.copy_(c)
+            with torch.cuda.stream(self._stream):
+                send = _dev_tensor(send_ptr, count)
+                recv = _dev_tensor(recv_ptr, count * self.world)
+                if self.world == 1:
+                    recv.copy_(send)
+                elif dist.get_backend() == "nccl":
+                    dist.all_gather_into_tensor(recv, send)
+                else:                       # gloo (tests): stage through the host
+                    c = send.cpu()
+                    parts = [torch.empty_like(c) for _ in range(self.world)]
+                    dist.all_gather(parts, c)
+                    recv.copy_(torch.cat(parts))
             return 0
         except Exception as e:          # never let an exception cross the C boundary
-            print("lpbox big all-reduce failed:", e)
+            print("lpbox big all-gather failed:", e)
             return 1
 
     def close(self):

@@ -163,18 +163,23 @@ int lpbox_debug_get_scalar(lpbox_t *h, int idx, const char *name, double *out);
 /* ---- LARGE single LP, variable-sharded over ranks (BASELINE config 5; no reference counterpart: the reference is one
  * process).  Rank r holds the columns [c0, c0+n_loc) of E (all l rows), its slice of b, and the full f; the l-vectors are
  * replicated.  Where the algorithm sums over all variables (E*v: an l-vector once per PCG iteration and twice per outer
- * iteration; <= 5 scalars per reduction) the library calls `fn(dev_ptr, count, user)`, which must sum `count` doubles at
- * dev_ptr in place over all ranks, stream-ordered on the stream given to lpbox_big_set_stream (RCCL all-reduce through
- * torch.distributed in lpbox_hip/big.py).  world == 1 issues no collective.  Semantics: ADMM_lp_iters (LPcpp:766-1095). */
+ * iteration; <= 5 scalars per reduction) the ranks exchange their contributions and EVERY rank adds them in rank order
+ * (c0 + c1) + c2 ..., so a W-rank run is reproducible and has an exact CPU model (oracle lpo_set_ranks).  Transport, chosen
+ * before lpbox_big_init:
+ *   - RCCL driven by the library itself on the handle's stream (lpbox_big_rccl_unique_id on one rank, the 128 bytes handed to
+ *     every rank by the caller's control plane, lpbox_big_rccl_init on every rank): per E*v one grouped send/recv of row blocks
+ *     (a reduce-scatter whose adds are ours) + one all-gather; per scalar group one all-gather.  No Python in the loop.
+ *   - or a caller-supplied all-gather `fn(send_dev, count, recv_dev, user)`: recv_dev[r*count .. (r+1)*count) := rank r's
+ *     send_dev[0..count), stream-ordered after the work already queued on the handle's stream (tests: gloo through torch).
+ * world == 1 without a transport issues no collective.  Semantics: ADMM_lp_iters (LPcpp:766-1095). */
 typedef struct lpbox_big lpbox_big_t;
-typedef int (*lpbox_allreduce_fn)(void *dev_ptr, long count, void *user);
+typedef int (*lpbox_allgather_fn)(const void *send_dev, long count, void *recv_dev, void *user);
 lpbox_big_t *lpbox_big_create(int rank, int world, int device);
 void lpbox_big_destroy(lpbox_big_t *h);
 int lpbox_big_set_stream(lpbox_big_t *h, void *hip_stream);
-int lpbox_big_set_allreduce(lpbox_big_t *h, lpbox_allreduce_fn fn, void *user);
-/* optional caller-owned device buffers for the two exchanged quantities (l doubles for E*v, 8 doubles for the scalars), so that
- * the all-reduce can run on the caller's own tensors (e.g. torch); call before lpbox_big_init */
-int lpbox_big_set_exchange(lpbox_big_t *h, void *q_dev, void *red_dev);
+int lpbox_big_set_allgather(lpbox_big_t *h, lpbox_allgather_fn fn, void *user);
+int lpbox_big_rccl_unique_id(void *out128);                    /* ncclGetUniqueId: 128 bytes, returns 128 */
+int lpbox_big_rccl_init(lpbox_big_t *h, const void *unique_id128);   /* ncclCommInitRank(world, id, rank) on the handle's device */
 int lpbox_big_set_problem(lpbox_big_t *h, long n_glob, int c0, int n_loc, int l, const int *colptr, const int *rowidx,
                           const double *b, const double *f);
 int lpbox_big_init(lpbox_big_t *h);                                             /* ADMM_lp_iters_init LPcpp:489-763 */

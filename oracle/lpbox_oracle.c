@@ -175,6 +175,9 @@ struct lpo {
     int *gpu_pos; int gpu_pos_n;   /* storage position of each original variable in the kernels (NULL = identity) */
     int gpu_npos;                  /* number of storage positions (>= org_n; holes contribute +0.0) */
     int gpu_chunk;                 /* > 0: two-level order of the large-instance kernels (workgroup partials of `chunk` positions) */
+    int gpu_ranks;                 /* > 1: the variable-sharded run (lpbox_big_*): contiguous blocks of variables per rank, every sum over
+                                      variables = per-rank sums (each in the order above, positions counted from the rank's first variable)
+                                      added in rank order p0 + p1 + p2 ... */
     int *row_G;                    /* GPU order: lanes that share row i of E (1,2,4,8); NULL = 1 */
     int *col_own, *col_help;       /* GPU order: split of the sum over column j of E (by ORIGINAL variable): own[j] leading entries,
                                       then chunks of help[4j+q] entries by quad lane q; NULL = unsplit */
@@ -184,10 +187,31 @@ struct lpo {
     int has_problem, inited;
 };
 
+/* first variable of rank rk when `total` variables are dealt in contiguous blocks to `world` ranks (lpbox_hip/dist.py shard_range) */
+static int rank_lo(int total, int world, int rk) {
+    const int base = total / world, extra = total % world;
+    return rk * base + (rk < extra ? rk : extra);
+}
+
 /* GPU order of a row of E (lpbox_lp_kernels.hip rows_gather): the kernels never compact E -- a fixed variable contributes
  * +0.0 -- and G = row_G[i] lanes share row i: lane g adds entries g, g+G, g+2G, ... (ascending column) starting from +0.0,
  * the G partials are combined by an xor butterfly.  full_v = the multiplied vector in ORIGINAL variable order. */
 static void spmv_orgE_split(lpo_t *o, const double *full_v, double *res) {
+    if (o->gpu_ranks > 1) {        /* every rank sums its own columns of the row (ascending), the rank partials are added in rank order */
+        const int W = o->gpu_ranks;
+        for (int i = 0; i < o->orgE.rows; i++) {
+            double total = 0.0;
+            int k = o->orgEr_ptr[i];
+            for (int rk = 0; rk < W; rk++) {
+                const int hi = rank_lo(o->org_n, W, rk + 1);
+                double part = 0.0;
+                for (; k < o->orgEr_ptr[i + 1] && o->orgEr_col[k] < hi; k++) part = part + o->orgEr_val[k] * (1.0 * full_v[o->orgEr_col[k]]);
+                total = rk == 0 ? part : total + part;
+            }
+            res[i] = total;
+        }
+        return;
+    }
     for (int i = 0; i < o->orgE.rows; i++) {
         const int G = o->row_G ? o->row_G[i] : 1;
         double part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -281,6 +305,7 @@ void lpo_set_order(lpo_t *o, int mode, int T) {
 
 void lpo_set_verbose(lpo_t *o, int verbose) { o->verbose = verbose; }
 void lpo_set_chunk(lpo_t *o, int chunk) { o->gpu_chunk = chunk > 0 ? chunk : 0; }
+void lpo_set_ranks(lpo_t *o, int ranks) { o->gpu_ranks = ranks > 1 ? ranks : 0; }
 
 void lpo_set_positions(lpo_t *o, const int *pos_of_var, int n, int npos) {
     free(o->gpu_pos);
@@ -382,13 +407,19 @@ static double reduce(lpo_t *o, const double *a, int cnt, const int *map) {
     else
         for (int i = 0; i < cnt; i++) o->full[map[i]] = a[i];
     if (o->gpu_chunk > 0) {        /* lpbox_big_kernels.hip: block tree per chunk, then the same tree over the chunk partials */
-        const int CH = o->gpu_chunk, Gn = (npos + CH - 1) / CH;
-        double *part = o->full + npos;
-        for (int g = 0; g < Gn; g++) {
-            int len = npos - g * CH; if (len > CH) len = CH;
-            part[g] = redux_sum_gpu_full(o->full + (size_t)g * CH, len, o->T);
+        const int CH = o->gpu_chunk, W = o->gpu_ranks > 1 ? o->gpu_ranks : 1;
+        double total = 0.0;
+        for (int rk = 0; rk < W; rk++) {
+            const int lo = rank_lo(npos, W, rk), hi = rank_lo(npos, W, rk + 1), nloc = hi - lo, Gn = (nloc + CH - 1) / CH;
+            double *part = o->full + npos;
+            for (int g = 0; g < Gn; g++) {
+                int len = nloc - g * CH; if (len > CH) len = CH;
+                part[g] = redux_sum_gpu_full(o->full + lo + (size_t)g * CH, len, o->T);
+            }
+            const double pr = redux_sum_gpu_full(part, Gn, o->T);
+            total = rk == 0 ? pr : total + pr;
         }
-        return redux_sum_gpu_full(part, Gn, o->T);
+        return total;
     }
     return redux_sum_gpu_full(o->full, npos, o->T);
 }

@@ -50,6 +50,8 @@ void lpo_set_col_split(lpo_t *o, const int *own, const int *help4, int n);
 /* GPU order of the LARGE-instance kernels: reductions are two-level (a block tree over every `chunk` consecutive positions, then
  * the same tree over the chunk partials).  0 = single workgroup (default). */
 void lpo_set_chunk(lpo_t *o, int chunk);
+/* GPU order of the variable-sharded run: `ranks` contiguous blocks of variables; per-rank sums added in rank order (needs lpo_set_chunk) */
+void lpo_set_ranks(lpo_t *o, int ranks);
 /* 1 = print the reference's stop messages to stdout (default 0 = quiet). */
 void lpo_set_verbose(lpo_t *o, int verbose);
 

@@ -43,6 +43,7 @@ def lib():
     L.lpo_set_order.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.lpo_set_verbose.argtypes = [C.c_void_p, C.c_int]
     L.lpo_set_chunk.argtypes = [C.c_void_p, C.c_int]
+    L.lpo_set_ranks.argtypes = [C.c_void_p, C.c_int]
     L.lpo_set_positions.argtypes = [C.c_void_p, _ip, C.c_int, C.c_int]
     L.lpo_set_row_split.argtypes = [C.c_void_p, _ip, C.c_int]
     L.lpo_set_col_split.argtypes = [C.c_void_p, _ip, _ip, C.c_int]
@@ -79,13 +80,15 @@ def lib():
 class LpOracle:
     """Mirror of the reference's PyLPboxADMMsolver (lpbox.pyx:7-76) on the CPU oracle."""
 
-    def __init__(self, print_info=0, order=ORDER_EIGEN, T=512, verbose=False, positions=None, npos=0, row_split=None, chunk=0, col_split=None):
+    def __init__(self, print_info=0, order=ORDER_EIGEN, T=512, verbose=False, positions=None, npos=0, row_split=None, chunk=0, col_split=None, ranks=0):
         self.L = lib()
         self.h = C.c_void_p(self.L.lpo_create(int(print_info)))
         self.L.lpo_set_order(self.h, order, T)
         self.L.lpo_set_verbose(self.h, int(verbose))
         if chunk:
             self.L.lpo_set_chunk(self.h, int(chunk))
+        if ranks:
+            self.L.lpo_set_ranks(self.h, int(ranks))
         if positions is not None:
             positions = np.ascontiguousarray(positions, np.int32)
             self.L.lpo_set_positions(self.h, positions, len(positions), int(npos))

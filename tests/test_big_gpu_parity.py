@@ -52,7 +52,7 @@ def test_single_rank_full_solve_bit_exact():
     assert g.cal_Obj() == o.cal_Obj()
 
 
-def _rank(rank, world, port, q):
+def _rank(rank, world, port, q, iters):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import sys
@@ -64,35 +64,64 @@ def _rank(rank, world, port, q):
     from lpbox_hip.synth import make_auction_like
     P = make_auction_like(6000, 5)
     g = BigLp(P, rank, world, device=0)
+    assert g.transport == "callback"
     g.solve_init()
-    g.solve_iter(0, 4)
-    q.put((rank, g.c0, g.local_x(), g.vec("z4"), g.scalar("cur_obj"), g.scalar("pcg_total"), g.scalar("collectives")))
+    g.solve_iter(0, iters)
+    q.put((rank, g.c0, g.local_x(), g.vec("z4"), g.scalar("cur_obj"), g.scalar("pcg_total"), g.scalar("collectives"),
+           g.vec("z1"), g.scalar("threads"), g.scalar("chunk"), g.scalar("outer_total")))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_variable_sharding_matches_single_rank():
+@pytest.mark.parametrize("world", [2, 3])
+def test_variable_sharded_ranks_bit_exact_against_oracle_rank_model(world):
+    """W ranks (all on the test box's one GPU, contributions exchanged over gloo) against the oracle's model of the rank partition
+    (per-rank sums added in rank order, oracle lpo_set_ranks): every iterate bit for bit -- not a comparison with a 1-rank HIP run."""
     import torch.multiprocessing as mp
-    from lpbox_hip.big import BigLp
     from lpbox_hip.synth import make_auction_like
+    iters = 12
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_rank, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_rank, args=(r, world, port, q, iters)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     P = make_auction_like(6000, 5)
-    g = BigLp(P)
+    o = O.LpOracle(0, order=O.ORDER_GPU, T=int(res[0][8]), chunk=int(res[0][9]), ranks=world)
+    o.set_problem(P["n"], P["l"], P["colptr"], P["rowidx"], P["b"])
+    o.solve_init()
+    o.solve_iter(0, iters)
+    assert bits_equal(np.concatenate([r[2] for r in res]), o.vec("x"))
+    assert bits_equal(np.concatenate([r[7] for r in res]), o.vec("z1"))
+    for r in res:                                               # replicated quantities: identical on every rank and equal to the oracle's
+        assert bits_equal(r[3], o.vec("z4")) and r[4] == o.scalar("cur_obj")
+        assert (r[10], r[5]) == (o.total_outer_iters, o.total_pcg_iters)
+        assert r[6] > 0
+    # and the rank order matters: the 1-rank association gives different bits (same PCG counts at this depth)
+    o1 = O.LpOracle(0, order=O.ORDER_GPU, T=int(res[0][8]), chunk=int(res[0][9]))
+    o1.set_problem(P["n"], P["l"], P["colptr"], P["rowidx"], P["b"])
+    o1.solve_init()
+    o1.solve_iter(0, iters)
+    assert not bits_equal(o1.vec("x"), o.vec("x")) and np.abs(o1.vec("x") - o.vec("x")).max() < 1e-3
+
+
+def test_rccl_self_communicator_single_rank():
+    """The RCCL transport (communicator created and driven by the library: grouped send/recv of row blocks, rank-ordered adds, all-gather)
+    on a ONE-rank communicator: the whole exchange path runs against itself on the single GPU of the test box and must leave the bits
+    of the plain single-rank run."""
+    from lpbox_hip.big import BigLp
+    from lpbox_hip.synth import make_auction_like
+    P = make_auction_like(20000, 0)
+    g = BigLp(P, transport="rccl")
     g.solve_init()
-    g.solve_iter(0, 4)
-    x = np.concatenate([res[0][2], res[1][2]])
-    # a different summation order across ranks: equal to rounding while the PCG iteration counts agree
-    assert res[0][5] == res[1][5] == g.scalar("pcg_total")
-    assert np.abs(x - g.local_x()).max() < 5e-4          # rounding x the PCG's error amplification
-    assert np.abs(res[0][3] - g.vec("z4")).max() < 5e-2 and bits_equal(res[0][3], res[1][3])   # replicated rows identical on both ranks
-    assert res[0][4] == res[1][4]
-    assert res[0][6] > 0
+    o = oracle_for(P, g)
+    for (a, b) in ((0, 5), (5, 40)):
+        assert g.solve_iter(a, b) == o.solve_iter(a, b)
+        for name in ("x", "z1", "z2", "z4"):
+            assert bits_equal(g.vec(name), o.vec(name)), (a, b, name)
+    assert g.scalar("collectives") > 40 * 10              # the exchanges really ran (>= 2 RCCL operations per E*v + the scalar groups)
+    assert (g.scalar("outer_total"), g.scalar("pcg_total")) == (o.total_outer_iters, o.total_pcg_iters)
