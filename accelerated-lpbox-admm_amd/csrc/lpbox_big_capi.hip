@@ -12,6 +12,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <map>
+#include <utility>
 #include <vector>
 
 #define HIPCHK(expr)                                                                                         \
@@ -74,6 +76,10 @@ struct lpbox_big {
     lpbox_allgather_fn ag = nullptr; void *ag_user = nullptr;   // exchange through the caller (tests: gloo) ...
     ncclComm_t comm = nullptr;                                  // ... or through RCCL, driven from here (no Python in the loop)
     long q_cap = 0;                                             // doubles allocated behind q (l rounded up to a multiple of world)
+    // launch-bound inner loop: BIG_ITERS_PER_GRAPH outer iterations captured once per (PCG launch count, start parity) and replayed
+    std::map<std::pair<int, int>, hipGraphExec_t> gexec; std::vector<hipGraph_t> graphs;
+    long long graph_launches = 0, graph_collectives = 0;       // of ONE replay (measured while capturing)
+    bool use_graph = true;
     int G = 0, Gl = 0, EPT = 2, EPTl = 2, kmax = 28, parity = 0;
     bool adaptive = true;
     double kernel_ms = 0.0; long long launches = 0, collectives = 0;
@@ -200,6 +206,36 @@ int read_state(lpbox_big *h) {
     return LPBOX_OK;
 }
 
+// An outer iteration is 8 + 3*kmax launches that flip the state ping-pong, so two iterations return to the parity they started
+// from: one hipGraph = BIG_ITERS_PER_GRAPH iterations per (kmax, start parity).  The caller's all-gather callback cannot be
+// captured (it runs host code at enqueue time); RCCL operations and the single-rank chain can.
+constexpr int BIG_ITERS_PER_GRAPH = 2;
+int ensure_graph(lpbox_big *h, const BigDev &d, hipGraphExec_t *out) {
+    const auto key = std::make_pair(h->kmax, h->parity);
+    auto it = h->gexec.find(key);
+    if (it != h->gexec.end()) { *out = it->second; return LPBOX_OK; }
+    const int par0 = h->parity;
+    const long long l0 = h->launches, c0 = h->collectives;
+    hipGraph_t g = nullptr;
+    HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    int rc = LPBOX_OK;
+    for (int i = 0; i < BIG_ITERS_PER_GRAPH && rc >= 0; i++) rc = enqueue_iteration(h, d);
+    const hipError_t e2 = hipStreamEndCapture(h->stream, &g);
+    h->graph_launches = h->launches - l0; h->graph_collectives = h->collectives - c0;
+    h->launches = l0; h->collectives = c0;
+    if (rc < 0 || e2 != hipSuccess || h->parity != par0) {
+        h->parity = par0;
+        if (g) (void)hipGraphDestroy(g);
+        return rc < 0 ? rc : lpbox_fail(LPBOX_E_HIP, "graph capture failed: %s", hipGetErrorString(e2));
+    }
+    hipGraphExec_t ex = nullptr;
+    HIPCHK(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
+    h->graphs.push_back(g);
+    h->gexec[key] = ex;
+    *out = ex;
+    return LPBOX_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -209,6 +245,7 @@ lpbox_big_t *lpbox_big_create(int rank, int world, int device) {
     lpbox_big *h = new lpbox_big();
     h->rank = rank; h->world = world; h->device = device;
     memset(&h->hst, 0, sizeof(h->hst));
+    if (getenv("LPBOX_BIG_NOGRAPH")) h->use_graph = false;                        // eager launches (profilers that dislike graphs)
     if (const char *e = getenv("LPBOX_BIG_KMAX")) { int v = atoi(e); if (v >= 1 && v <= 1000) { h->kmax = v; h->adaptive = false; } }
     return h;
 }
@@ -221,6 +258,8 @@ void lpbox_big_destroy(lpbox_big_t *h) {
     for (Buf<double> *bp : {&h->x, &h->y1, &h->y2, &h->z1, &h->z2, &h->db, &h->pd, &h->dinv, &h->rhs, &h->r, &h->z, &h->tmp, &h->p0, &h->p1,
                             &h->gsrc, &h->y3, &h->z4, &h->df, &h->fy, &h->Ex, &h->q, &h->part, &h->red, &h->xt, &h->xhist, &h->xi_out, &h->gath, &h->flag})
         bp->release();
+    for (auto &kv : h->gexec) (void)hipGraphExecDestroy(kv.second);
+    for (hipGraph_t g : h->graphs) (void)hipGraphDestroy(g);
     if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(h->comm);
     h->st.release(); h->live.release(); h->newfix.release(); h->d_live_idx.release(); h->zp.release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -358,7 +397,15 @@ static int run_window(lpbox_big *h, const BigDev &d, int iter_end) {
         if (remaining <= 0 && !h->hst.have_prev) break;
         if (h->adaptive && h->hst.outer_total > 0) h->kmax = std::max(4, h->hst.pcg_max + 3);
         HIPCHK(big_launch_resume(d, 1, &h->parity, h->stream));
-        const int batch = std::min(std::max(remaining, 0), 16);
+        int batch = std::min(std::max(remaining, 0), 16);
+        if (h->use_graph && !h->ag && batch >= BIG_ITERS_PER_GRAPH) {
+            hipGraphExec_t ex = nullptr;
+            CHK(ensure_graph(h, d, &ex));
+            for (; batch >= BIG_ITERS_PER_GRAPH; batch -= BIG_ITERS_PER_GRAPH) {
+                HIPCHK(hipGraphLaunch(ex, h->stream));
+                h->launches += h->graph_launches; h->collectives += h->graph_collectives;
+            }
+        }
         for (int it = 0; it < batch; it++) CHK(enqueue_iteration(h, d));
         HIPCHK(big_launch_prep(d, 0, &h->parity, h->stream)); h->launches++;          // finalise the last iteration of the batch
     }
@@ -414,6 +461,8 @@ int lpbox_big_iterate_l2f(lpbox_big_t *h, int iter_start, int iter_end, const do
     if (ws > 0 && (h->ws_cap < ws || !h->xhist.p)) {
         HIPCHK(hipStreamSynchronize(h->stream));
         HIPCHK(h->xhist.alloc((size_t)ws * h->n_loc));
+        for (auto &kv : h->gexec) (void)hipGraphExecDestroy(kv.second);         // the captured launches carry the old window buffer
+        h->gexec.clear();
         h->ws_cap = ws;
     }
     const BigDev d = h->dev();
