@@ -94,6 +94,7 @@ struct lpbox_solver {
     std::vector<LpInstance> inst;
     bool finalized = false, inited = false;
     int NS = 0, LS = 0, ZS = 0, T = 0, EPT = 0;
+    bool colsplit = false;
     size_t lds = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -164,14 +165,15 @@ int finalize(lpbox_t *h) {
     // largest instances use 4 wavefronts x 8 slots so that each lane may take the whole 512-entry register file.
     // LPBOX_LP_THREADS overrides (tuning only).
     const int big = std::max(nmax, lmax);
-    int T = big > 1024 ? 256 : 512;
-    if (const char *e = getenv("LPBOX_LP_THREADS")) { int v = atoi(e); if (v == 256 || v == 512) T = v; }
-    const int max_ept = T == 256 ? 8 : 2;
+    int T = 512;
+    if (const char *e = getenv("LPBOX_LP_THREADS")) { int v = atoi(e); if (v == 256 || v == 512 || v == 1024) T = v; }
+    const int max_ept = T == 256 ? 8 : (T == 1024 ? 1 : 4);
     int EPT = 1;
     while (EPT < max_ept && (long)T * EPT < big) EPT *= 2;
     if ((long)T * EPT < big && T == 512) { T = 256; EPT = 1; while (EPT < 8 && (long)T * EPT < big) EPT *= 2; }
     if ((long)T * EPT < big)
         return fail(LPBOX_E_UNSUPPORTED, "instance with max(n,l)=%d exceeds the on-chip kernel's %d register slots", big, T * EPT);
+    h->colsplit = T == 512 || T == 1024;                                        // variants compiled with helper lists (LP_DISPATCH)
     h->T = T; h->EPT = EPT;
     h->NS = T * EPT;                       // storage positions / row-task slots per instance
     h->LS = (lmax + 31) & ~31; h->ZS = (zmax + 7) & ~7;     // LS: a whole number of 32-row bank classes
@@ -277,7 +279,7 @@ int finalize(lpbox_t *h) {
             for (auto &o : occ[j]) cnt[((size_t)o.first * max_chain + o.second) * 32 + (p % 32)]++;
             I.cpos[j] = p; var_of_pos[p] = j;
         };
-        const bool colsplit = h->EPT == 1 && !nosort && getenv("LPBOX_LP_NOCOLSPLIT") == nullptr;
+        const bool colsplit = h->colsplit && !nosort && getenv("LPBOX_LP_NOCOLSPLIT") == nullptr;
         if (nosort) {
             for (int qq = 0; qq < I.n; qq++) { I.cpos[I.cperm[qq]] = qq; var_of_pos[qq] = I.cperm[qq]; }
         } else if (!colsplit) {
@@ -331,12 +333,13 @@ int finalize(lpbox_t *h) {
             }
             // lane of every column: bank-aware greedy as above, inside the wave's free quad slots / the quad's free lanes
             std::vector<char> used(NS, 0), slot_used(Q, 0);
+            auto qbase = [&](int w) { return block_base(w) / 4; };    // first quad slot of the 64 positions that hold logical block w
             for (int qq = 0; qq < I.n; qq++) {
                 const int j = I.cperm[qq];
                 Quad &qd = quad[quad_of_var[j]];
                 const int w = quad_of_var[j] / QW;
                 int best = -1; long best_cost = 0;
-                for (int t = (qd.slot >= 0 ? qd.slot : w * QW); t < (qd.slot >= 0 ? qd.slot + 1 : (w + 1) * QW); t++) {
+                for (int t = (qd.slot >= 0 ? qd.slot : qbase(w)); t < (qd.slot >= 0 ? qd.slot + 1 : qbase(w) + QW); t++) {
                     if (qd.slot < 0 && slot_used[t]) continue;
                     for (int p = 4 * t; p < 4 * t + 4; p++) {
                         if (used[p]) continue;
@@ -351,7 +354,7 @@ int finalize(lpbox_t *h) {
             for (int qd_i = 0; qd_i < Q; qd_i++) {               // quads made of holes only still need a slot (nothing is stored there)
                 Quad &qd = quad[qd_i];
                 if (qd.slot >= 0) continue;
-                for (int t = (qd_i / QW) * QW; t < (qd_i / QW + 1) * QW; t++) if (!slot_used[t]) { qd.slot = t; slot_used[t] = 1; break; }
+                for (int t = qbase(qd_i / QW); t < qbase(qd_i / QW) + QW; t++) if (!slot_used[t]) { qd.slot = t; slot_used[t] = 1; break; }
             }
             // chunks of the tails, in lane order over the helper lanes of the quad
             I.help_of_pos.assign(NS, {-1, 0, 0});

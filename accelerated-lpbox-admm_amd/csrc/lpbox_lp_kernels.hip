@@ -864,7 +864,9 @@ size_t lp_window_lds_bytes(int T, int NS, int LS, int ZS) {
     else if (T == 256 && EPT == 4) { KERNEL_CALL(256, 4, (Caps<12, 12, 12, 12>), (Caps<24, 8, 8, 8>), (Caps<0, 0, 0, 0>)) }                  \
     else if (T == 256 && EPT == 8) { KERNEL_CALL(256, 8, (Caps<8, 8, 8, 8, 8, 8, 8, 8>), (Caps<8, 8, 8, 8, 4, 4, 4, 4>), (Caps<0, 0, 0, 0, 0, 0, 0, 0>)) } \
     else if (T == 512 && EPT == 1) { KERNEL_CALL(512, 1, (Caps<12>), (Caps<12>), (Caps<8>)) }                                                \
-    else if (T == 512 && EPT == 2) { KERNEL_CALL(512, 2, (Caps<12, 12>), (Caps<16, 8>), (Caps<0, 0>)) }                                      \
+    else if (T == 512 && EPT == 2) { KERNEL_CALL(512, 2, (Caps<12, 12>), (Caps<12, 8>), (Caps<8, 4>)) }                                      \
+    else if (T == 512 && EPT == 4) { KERNEL_CALL(512, 4, (Caps<8, 8, 8, 8>), (Caps<8, 8, 8, 8>), (Caps<4, 4, 4, 4>)) }                        \
+    else if (T == 1024 && EPT == 1) { KERNEL_CALL(1024, 1, (Caps<8>), (Caps<8>), (Caps<8>)) }                                                \
     else return hipErrorInvalidConfiguration;
 
 #define LP_UNPAREN(...) __VA_ARGS__

@@ -326,6 +326,61 @@ class PyLPboxADMMsolver:
         self._echo_stop(plain=False)
         return ret
 
+    # not in the pyx: ADMM_lp_iters_fix (LPcpp:1689-2286), the rule-based early fixing the C++ class carries but exposes to no caller
+    def solve_iter_fix(self, i, j, consistency=5, fix_threshold=1e-3, min_fix=10):
+        """Iterations [i, j) with the persistence rule of ADMM_lp_iters_fix: a variable whose iterate moved by <= fix_threshold
+        for `consistency` consecutive iterations is flagged (LPcpp:1857-1871); once more than `min_fix` variables are flagged
+        (:1932) they are fixed at their rounded value (:2006) and leave the problem.
+
+        REPAIRED semantics, stated once: as written, the reference's fix branch (tmp == 1, :1935-2043) compacts x, y, z, b, E and f
+        but never rebuilds E^T, rho4*E^T, the diagonal and the preconditioner (no update_expression), so its next iteration adds
+        vectors of the old and the new length (:1777-1783) -- an Eigen assertion / out-of-bounds access: the function cannot run
+        past its first fix, and nothing calls it.  Here a fix is the fix block of ADMM_lp_iters_l2f (:1124-1335, which the dead
+        tmp == 2 branch :2045-2280 copies, update_expression included), and the per-variable counters follow their variable
+        through the compaction (the reference would index counters of the old length with new indices, :1861-1871).
+        Everything else is the loop as written: counters re-zeroed per call (:1702-1703), x_prev kept across calls (:572, :1871),
+        z4 always accumulated, y1_y2 stop returns 0 (:1880-1886), obj_std stop and a failed PCG return 1 (:1804-1807, :1913).
+        Host-driven: one single-iteration l2f window per iteration (the rule needs every iterate on the host anyway)."""
+        i, j = _as_int(i, "i"), _as_int(j, "j")
+        n_live = self._b.get_n(0)
+        prev = getattr(self, "_x_prev", None)
+        if prev is None or prev.shape[0] != n_live:
+            prev = np.zeros(n_live)                                   # x_prev = Zero(n) (:572)
+        count, flag = np.zeros(n_live), np.zeros(n_live, bool)
+        vec, num, ret = None, 0, 0
+        for it in range(i, j):
+            r = self.solve_iter_l2f(it, it + 1, vec if num else np.zeros(n_live), num)
+            if num:                                                    # the fix went in at the start of this call
+                keep = vec == -1
+                prev, count, flag = prev[keep], count[keep], flag[keep]
+                n_live = int(keep.sum())
+                vec, num = None, 0
+            reason, _ = self._b.stop(0)
+            if reason in (3, 4) or (r and reason == 0):                # PCG alpha < 0 (:1804-1807) / everything fixed / |x| < 1e-3 (:2000)
+                ret = 1
+                break
+            x = self._b.get_x_iters_2d(1, 0)[:, 0]
+            det = np.abs(x - prev) <= fix_threshold                    # :1861
+            count = np.where(det, count + 1, 0.0)
+            flag |= det & (count >= consistency)
+            prev = x.copy()                                            # :1871
+            if reason == 1:                                            # y1_y2: break, ret stays 0 (:1880-1886)
+                break
+            if reason == 2:                                            # obj_std (:1913-1919)
+                ret = 1
+                break
+            fix_n = int(flag.sum())                                    # :1929-1932
+            if fix_n > min_fix:
+                vec = np.where(flag, np.where(x >= 0.5, 1.0, 0.0), -1.0)
+                num = fix_n
+        if num:                                                        # a fix decided by the last iteration goes in now (:1935), zero-length window
+            r = self.solve_iter_l2f(j, j, vec, num)
+            keep = vec == -1
+            prev = prev[keep]
+            ret = ret or int(r)
+        self._x_prev = prev
+        return ret
+
     # LP pyx:35-41
     def get_x_iters_1d(self, ws):
         ws = _as_int(ws, "ws")

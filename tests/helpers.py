@@ -173,3 +173,45 @@ def scripted_scores(x, hi=0.985, lo=0.015):
     x = torch.as_tensor(x, dtype=torch.float32)
     m = x[:, -1, :].mean(dim=1)
     return torch.where(m > hi, 0.95, torch.where(m < lo, 0.05, 0.5)).to(torch.float32)
+
+
+def oracle_iters_fix(o, i, j, x_prev=None, consistency=5, fix_threshold=1e-3, min_fix=10):
+    """ADMM_lp_iters_fix (LPcpp:1689-2286) restated in the reference's OWN order on the oracle's primitives: one iteration, the
+    persistence counters (:1857-1871), the stop tests, then the fix AT THE END of the iteration (:1929-2043) -- applied here
+    through a zero-length l2f call, i.e. the repaired fix block (see lpbox_hip.lp.PyLPboxADMMsolver.solve_iter_fix).
+    Returns (ret, x_prev)."""
+    n = o.get_n()
+    prev = np.zeros(n) if x_prev is None or len(x_prev) != n else x_prev
+    count, flag = np.zeros(n), np.zeros(n, bool)
+    ret = 0
+    for it in range(i, j):
+        r = o.solve_iter_l2f(it, it + 1, np.zeros(n), 0)
+        reason = o.last_stop_reason
+        if reason in (3, 4) or (r and reason == 0):
+            return 1, prev
+        x = o.get_x_iters_2d(1)[:, 0]
+        for k in range(n):                                   # the reference's loop, element by element
+            if abs(x[k] - prev[k]) <= fix_threshold:
+                count[k] += 1
+                if count[k] >= consistency:
+                    flag[k] = True
+            else:
+                count[k] = 0
+        prev = x.copy()
+        if reason == 1:
+            break
+        if reason == 2:
+            ret = 1
+            break
+        fix_n = int(flag.sum())
+        if fix_n <= min_fix:
+            continue
+        vec = np.where(flag, np.where(x >= 0.5, 1.0, 0.0), -1.0)
+        r = o.solve_iter_l2f(it + 1, it + 1, vec, fix_n)     # the fix block alone
+        keep = ~flag
+        prev, count, flag = prev[keep], count[keep], flag[keep]
+        n = int(keep.sum())
+        if r:
+            ret = 1
+            break
+    return ret, prev
