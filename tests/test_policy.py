@@ -68,13 +68,13 @@ def test_fused_encoder_matches_reference_gpu(tag, tokens):
     (b) against the fp32 evaluation with weights drawn like the reference initialises them (mha.py:52-56), on a ragged row
         count (tail workgroup): 2e-4 on the sigmoid."""
     sd = deterministic_state(P.reference_state_shapes(tokens))
-    fused = P.FusedEarlyFixPolicy(sd, tokens=tokens, device="cuda")
+    fused = P.FusedEarlyFixPolicy(sd, tokens=tokens, device="cuda", decision_band=0)        # the bare fp16 path
     x = torch.from_numpy(FIX[tag + "_x"]).cuda()
     assert np.abs(fused(x).cpu().numpy() - FIX[tag + "_sigmoid"]).max() < 2e-2
     h16 = P.EarlyFixPolicy(sd, tokens=tokens, device="cuda", dtype=torch.float16)
     assert (fused.logits(x) - h16.logits(x)).abs().max().item() < 3e-2          # same arithmetic class as torch's fp16 path
     sd = P.random_state(tokens, seed=1)
-    fused, ref = P.FusedEarlyFixPolicy(sd, tokens=tokens, device="cuda"), P.EarlyFixPolicy(sd, tokens=tokens, device="cuda")
+    fused, ref = P.FusedEarlyFixPolicy(sd, tokens=tokens, device="cuda", decision_band=0), P.EarlyFixPolicy(sd, tokens=tokens, device="cuda")
     xr = torch.rand(1003, tokens, 5, generator=torch.Generator().manual_seed(3)).cuda()
     assert (fused(xr) - ref(xr)).abs().max().item() < 2e-4
     # x_iters-style input: fp64 buffer + row offsets, rows in arbitrary order
@@ -82,6 +82,32 @@ def test_fused_encoder_matches_reference_gpu(tag, tokens):
     perm = torch.randperm(1003, generator=torch.Generator().manual_seed(4)).cuda()
     got = fused.scores_from_xiters(flat, perm * (tokens * 5))
     assert (got - ref(xr)[perm]).abs().max().item() < 2e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,tokens", [("lp", 20), ("seg", 5)])
+def test_fused_policy_takes_the_fp32_fix_decisions(tag, tokens):
+    """deter_fix_2 thresholds the score at 0.9 / 0.1: with the default decision band the fused path re-scores the rows near a
+    threshold in fp32, so its FIX VECTOR equals the one the fp32 network (= the reference's arithmetic, pinned by the golden
+    vectors above) produces -- on the reference-generated fixture (stress weights: fp16 alone is off by up to 2e-2 there) and on
+    random inputs with reference-style weights; and the band is not vacuous: without it the stress fixture does flip decisions
+    or at least moves scores across the band."""
+    from lpbox_hip.l2f import fix_vector_from_scores
+    sd = deterministic_state(P.reference_state_shapes(tokens))
+    x = torch.from_numpy(FIX[tag + "_x"]).cuda()
+    fused, ref = P.FusedEarlyFixPolicy(sd, tokens=tokens, device="cuda"), P.EarlyFixPolicy(sd, tokens=tokens, device="cuda")
+    want = fix_vector_from_scores(FIX[tag + "_sigmoid"])                    # decisions of the reference module itself
+    got = fix_vector_from_scores(fused(x).cpu().numpy())
+    assert np.array_equal(got[0], want[0]) and got[1:] == want[1:]
+    sd = P.random_state(tokens, seed=2)
+    fused, ref = P.FusedEarlyFixPolicy(sd, tokens=tokens, device="cuda"), P.EarlyFixPolicy(sd, tokens=tokens, device="cuda")
+    g = torch.Generator().manual_seed(7)
+    xr = torch.rand(20000, tokens, 5, generator=g)
+    xr[:8000] = torch.round(xr[:8000])                                      # converged iterates sit at 0 / 1
+    xr = xr.cuda()
+    a, b = fix_vector_from_scores(fused(xr).cpu().numpy()), fix_vector_from_scores(ref(xr).cpu().numpy())
+    assert np.array_equal(a[0], b[0])
+    assert fused.rescored < 0.5 * 20000                                     # the fp32 pass stays a side path
 
 
 @pytest.mark.parametrize("tag,tokens", [("lp", 20), ("seg", 5)])
