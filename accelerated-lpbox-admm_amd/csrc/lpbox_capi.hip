@@ -211,7 +211,9 @@ int finalize(lpbox_t *h) {
         const int wv = (slot & 1) ? (W - 1 - r) : r;
         return slot * h->T + wv * 64;
     };
-    const bool noconflict = getenv("LPBOX_LP_NOCONFLICT") != nullptr;
+    // bank-aware lane choice (round 1): worth < 2 % per iteration once long columns are split, and O(n * 32 * row length) host work;
+    // off by default, LPBOX_LP_BANKAWARE=1 turns it on (tools/lottery.sh measures both)
+    const bool noconflict = getenv("LPBOX_LP_BANKAWARE") == nullptr || getenv("LPBOX_LP_NOCONFLICT") != nullptr;
     for (size_t i = 0; i < B; i++) {
         LpInstance &I = h->inst[i];
         // ---- rows: G lanes share a row so that no lane walks more than ~L entries; lane g takes entries g, g+G, ... ----
@@ -310,6 +312,7 @@ int finalize(lpbox_t *h) {
             // keeps its first tau entries (tau = longest companion), the rest is dealt in consecutive chunks to the other three
             // lanes (helper lists, summed into a second accumulator and combined over the quad, lp_window_kernel cols_gather).
             const int Q = (int)NS / 4, QW = 16, CH = 8;           // quads, quads per wave, register capacity of a helper list
+            const int split_bias = getenv("LPBOX_LP_SPLITBIAS") ? atoi(getenv("LPBOX_LP_SPLITBIAS")) : 2;   // cost of the quad combine, in list entries (tuning)
             auto var_of_rank = [&](int r) { return r < I.n ? I.cperm[r] : -1; };
             struct Quad { int v[4]; int tau, tail, slot; };
             std::vector<Quad> quad(Q);
@@ -328,7 +331,7 @@ int finalize(lpbox_t *h) {
                     A = std::max(A, std::max(qd.tau, s1)); Bm = std::max(Bm, (qd.tail + 2) / 3); Lm = std::max(Lm, std::max(L, s1));
                     for (int t = 0; t < 4; t++) if (qd.v[t] >= 0) quad_of_var[qd.v[t]] = w * QW + qi;
                 }
-                if (r2(A) + r2(Bm) + 1 >= r2(Lm))                 // splitting does not shorten this wave's longest list
+                if (r2(A) + r2(Bm) + split_bias >= r2(Lm))        // splitting does not shorten this wave's longest list
                     for (int qi = 0; qi < QW; qi++) { Quad &qd = quad[w * QW + qi]; qd.tau = clen(qd.v[0]); qd.tail = 0; }
             }
             // lane of every column: bank-aware greedy as above, inside the wave's free quad slots / the quad's free lanes

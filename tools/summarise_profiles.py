@@ -23,6 +23,8 @@ def counter(path, name, kernel_substr):
 
 
 stats(os.path.join(O, "prof_bench", "bench_kernel_stats.csv"), os.path.join(P, rnd + "_kernel_stats.csv"))
+if os.path.exists(os.path.join(O, "prof_c4", "c4_kernel_stats.csv")):
+    stats(os.path.join(O, "prof_c4", "c4_kernel_stats.csv"), os.path.join(P, rnd + "_config4_kernel_stats.csv"))
 stats(os.path.join(O, "prof_policy", "policy_kernel_stats.csv"), os.path.join(P, rnd + "_policy_kernel_stats.csv"))
 stats(os.path.join(O, "prof_big", "big_kernel_stats.csv"), os.path.join(P, rnd + "_big_kernel_stats.csv"))
 stats(os.path.join(O, "prof_seg", "seg_kernel_stats.csv"), os.path.join(P, rnd + "_seg_kernel_stats.csv"))
@@ -30,7 +32,8 @@ fetch_kb, nf = counter(os.path.join(O, "prof_fetch", "fetch_counter_collection.c
 write_kb, nw = counter(os.path.join(O, "prof_write", "write_counter_collection.csv"), "WRITE_SIZE", "lp_window_kernel")
 out = {
     "command": "rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python3 bench.py --steps 2 --warmup 1 --cpu-sample 0 ; same with --pmc WRITE_SIZE (two separate passes, tools/collect_profiles.sh)",
-    "kernel": "lp_window_kernel<512,1,Caps<12>,Caps<24>>",
+    "kernel": "lp_window_kernel<512,1> (config 2: 256 instances j=100/k=500)",
+    "instances": 256,
     "launches_sampled": [nf, nw],
     "FETCH_SIZE_KB_per_launch": fetch_kb,
     "WRITE_SIZE_KB_per_launch": write_kb,
@@ -44,3 +47,5 @@ for name in ("prof_bench", "prof_policy", "prof_big", "prof_seg"):
     for ln in open(log):
         if ln.startswith("{") or ln.startswith("rows ") or ln.startswith("n="):
             print(name, ln.strip()[:300])
+        if ln.startswith("{") and name in ("prof_bench", "prof_c4", "prof_big", "prof_seg"):     # the bench line of the profiled run itself
+            open(os.path.join(P, rnd + "_" + name[5:] + "_bench_line.json"), "w").write(ln)
