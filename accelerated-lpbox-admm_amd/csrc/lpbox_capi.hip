@@ -165,7 +165,7 @@ int finalize(lpbox_t *h) {
     // largest instances use 4 wavefronts x 8 slots so that each lane may take the whole 512-entry register file.
     // LPBOX_LP_THREADS overrides (tuning only).
     const int big = std::max(nmax, lmax);
-    int T = 512;
+    int T = big > 1024 ? 256 : 512;       // n = 2000: 256 x 8 measured faster over a whole solve than 512 x 4 (both spill; LPBOX_LP_THREADS tries the other)
     if (const char *e = getenv("LPBOX_LP_THREADS")) { int v = atoi(e); if (v == 256 || v == 512 || v == 1024) T = v; }
     const int max_ept = T == 256 ? 8 : (T == 1024 ? 1 : 4);
     int EPT = 1;
