@@ -1163,6 +1163,17 @@ int lpbox_seg_legacy(lpbox_t *h, int *energy) {
     return segc_legacy(h->seg, energy);
 }
 
+int lpbox_seg_legacy_batch(lpbox_t **hs, int count, int *energies) {
+    if (!hs || count <= 0) return fail(LPBOX_E_BADARG, "empty batch");
+    std::vector<SegSolver *> ss(count);
+    for (int i = 0; i < count; i++) {
+        int rc = seg_handle(hs[i]);
+        if (rc) return rc;
+        ss[i] = hs[i]->seg;
+    }
+    return segc_legacy_batch(ss.data(), count, energies);
+}
+
 int lpbox_seg_get_obj(lpbox_t *h, double *out) {
     int rc = seg_handle(h);
     if (rc) return rc;

@@ -13,6 +13,7 @@ int segc_set_problem(SegSolver *s, int n, int nnz, const int *rowptr, const int 
 int segc_set_image(SegSolver *s, const unsigned char *gray, int rows, int cols, int num_nodes);
 int segc_init(SegSolver *s);
 int segc_legacy(SegSolver *s, int *energy);
+int segc_legacy_batch(SegSolver **ss, int count, int *energies);
 int segc_l2f(SegSolver *s, int iter_start, int iter_end, const double *vec, int num, int *ret);
 int segc_get_n(SegSolver *s);
 int segc_get_org_n(SegSolver *s);

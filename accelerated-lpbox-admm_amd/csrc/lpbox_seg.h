@@ -64,6 +64,7 @@ struct SegDev {
     double *part;           // [phase(5)][SEG_NPART][Gmax]
     double *xhist; int ws_cap;
     SegState *st;           // st[0], st[1] ping-pong
+    double c1_init;         // pow(n, 1/2) for the batched init (SEGcpp:557,670)
 };
 
 hipError_t seg_launch_init(const SegDev &d, double c1, hipStream_t s);
@@ -76,3 +77,14 @@ hipError_t seg_enqueue_pcg_more(const SegDev &d, int pairs, int *parity, hipStre
 hipError_t seg_enqueue_finalize(const SegDev &d, int *parity, hipStream_t s);              // finalise the last iteration only
 hipError_t seg_launch_copy(const SegDev &d, int reset_pcg_max, int *parity, hipStream_t s);   // state copy (parity flip), optionally pcg_max = 0
 hipError_t seg_launch_pack_xiters(const SegDev &d, const int *live_idx, int rows, int ws, double *out, hipStream_t s);
+
+// Batches of problems advanced in lockstep by ONE launch chain (devs = device array of B descriptors, grid (Gmax, B)): the kernels are
+// the same bodies; every problem keeps its own control state, partial sums and iteration counts, so a problem whose PCG has converged
+// or that has stopped falls through while the others go on.
+hipError_t segb_launch_init(const SegDev *devs, int B, int Gmax, hipStream_t s);
+hipError_t segb_launch_set_window(const SegDev *devs, int B, int iter_start, int iter_end, int mode, int *parity, hipStream_t s);
+hipError_t segb_launch_copy(const SegDev *devs, int B, int reset_pcg_max, int *parity, hipStream_t s);
+hipError_t segb_enqueue_iterations(const SegDev *devs, int B, int Gmax, int iters, int kmax, int *parity, hipStream_t s);
+hipError_t segb_enqueue_pcg_more(const SegDev *devs, int B, int Gmax, int pairs, int *parity, hipStream_t s);
+hipError_t segb_enqueue_finalize(const SegDev *devs, int B, int Gmax, int *parity, hipStream_t s);
+hipError_t segb_collect_states(const SegDev *devs, int B, int parity, SegState *out, hipStream_t s);

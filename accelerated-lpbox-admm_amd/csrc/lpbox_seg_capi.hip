@@ -62,6 +62,7 @@ struct SegSolver {
         d.x = x.p; d.y1 = y1.p; d.y2 = y2.p; d.z1 = z1.p; d.z2 = z2.p; d.b = b.p; d.rhs = rhs.p; d.r = r.p; d.z = z.p;
         d.tmp = tmp.p; d.dinv = dinv.p; d.td = td.p; d.p0 = p0.p; d.p1 = p1.p; d.live = live.p; d.fixval = fixval.p;
         d.newfix = newfix.p; d.part = part.p; d.xhist = xhist.p; d.ws_cap = ws_cap; d.st = st.p;
+        d.c1_init = std::pow((double)n, 1.0 / 2);      // pow(n, 1/p), p = 2 (SEGcpp:557,670)
         return d;
     }
 };
@@ -365,6 +366,90 @@ int segc_legacy(SegSolver *s, int *energy) {                                  //
     s->rec_cols = s->record > 0 ? std::min(s->hst.cc, s->ws_cap) : 0;
     s->xi_valid = false;
     if (energy) *energy = (int)(s->hst.cur_obj + s->c);                        // :1379
+    return LPBOX_OK;
+}
+
+// ADMM_bqp_unconstrained_init + _legacy (SEGcpp:658-810, 1200-1380) for B problems advanced in LOCKSTEP by one launch chain
+// (image_segmentation.cpp:24-29 solves images 0..99 at 10^4 nodes one after the other: there a solve is launch-bound and the GPU
+// mostly idle).  Every problem keeps its own control state, so the arithmetic of each is exactly that of a solve on its own.
+int segc_legacy_batch(SegSolver **ss, int B, int *energies) {
+    if (!ss || B <= 0) return lpbox_fail(LPBOX_E_BADARG, "empty batch");
+    SegSolver *s0 = ss[0];
+    for (int i = 0; i < B; i++) {
+        if (!ss[i] || !ss[i]->has_problem) return lpbox_fail(LPBOX_E_STATE, "problem %d of the batch has no image / problem", i);
+        if (ss[i]->device != s0->device) return lpbox_fail(LPBOX_E_BADARG, "all problems of a batch must live on one device");
+        if (ss[i]->record > 0) return lpbox_fail(LPBOX_E_UNSUPPORTED, "recording is per-solver (lpbox_seg_legacy)");
+    }
+    int rc = LPBOX_OK;
+    int Gmax = 0;
+    for (int i = 0; i < B; i++) {                                   // upload + host-side reset of segc_init (the init KERNEL runs batched)
+        SegSolver *s = ss[i];
+        rc = s->uploaded ? use_device(s) : upload(s);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(s->b.p, s->orgb.data(), sizeof(double) * (size_t)s->n, hipMemcpyHostToDevice, s->stream));
+        s->left_idx.resize(s->n);
+        for (int k = 0; k < s->n; k++) s->left_idx[k] = k;
+        s->xi_valid = false; s->parity = 0; s->inited = true;
+        Gmax = std::max(Gmax, s->G);
+    }
+    for (int i = 0; i < B; i++) HIPCHK(hipStreamSynchronize(ss[i]->stream));
+    hipStream_t st = s0->stream;
+    std::vector<SegDev> hd(B);
+    for (int i = 0; i < B; i++) hd[i] = ss[i]->dev();
+    Buf<SegDev> devs; Buf<SegState> dstates;
+    HIPCHK(devs.alloc(B)); HIPCHK(dstates.alloc(B));
+    HIPCHK(hipMemcpyAsync(devs.p, hd.data(), sizeof(SegDev) * (size_t)B, hipMemcpyHostToDevice, st));
+    std::vector<SegState> hs(B);
+    int parity = 0, kmax = s0->kmax;
+    long long launches = 0;
+    auto read_states = [&]() -> int {
+        HIPCHK(segb_collect_states(devs.p, B, parity, dstates.p, st));
+        HIPCHK(hipMemcpyAsync(hs.data(), dstates.p, sizeof(SegState) * (size_t)B, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        return LPBOX_OK;
+    };
+    HIPCHK(hipEventRecord(s0->ev0, st));
+    HIPCHK(segb_launch_init(devs.p, B, Gmax, st));
+    HIPCHK(segb_launch_set_window(devs.p, B, 0, SEG_MAX_ITERS, 0, &parity, st));
+    launches += 2;
+    for (;;) {
+        rc = read_states();
+        if (rc) { devs.release(); dstates.release(); return rc; }
+        bool more = false, any_run = false;
+        int remaining = 0, pcg_max = 0, pcg_k = 0;
+        for (int i = 0; i < B; i++) {
+            const SegState &h = hs[i];
+            if (h.halt == SEG_HALT_PCG_MORE) { more = true; pcg_k = std::max(pcg_k, h.pcg_k); continue; }
+            if (h.halt != SEG_HALT_NONE) continue;
+            const int rem = SEG_MAX_ITERS - h.iter;
+            if (rem <= 0 && !h.have_prev) continue;
+            any_run = true; remaining = std::max(remaining, rem); pcg_max = std::max(pcg_max, h.outer_total > 0 ? h.pcg_max : kmax - 2);
+        }
+        if (more) {                                                 // some PCG ran out of launches: resume it (the others fall through)
+            HIPCHK(segb_enqueue_pcg_more(devs.p, B, Gmax, 16, &parity, st));
+            launches += 34;
+            if (s0->adaptive) kmax = std::min(SEG_KMAX_LIMIT, std::max(kmax, pcg_k + 4));
+            continue;
+        }
+        if (!any_run) break;
+        if (s0->adaptive) kmax = std::min(SEG_KMAX_LIMIT, std::max(2, pcg_max + 2));
+        HIPCHK(segb_launch_copy(devs.p, B, 1, &parity, st));
+        const int batch = std::min(std::max(remaining, 0), 32);
+        if (batch > 0) HIPCHK(segb_enqueue_iterations(devs.p, B, Gmax, batch, kmax, &parity, st));
+        HIPCHK(segb_enqueue_finalize(devs.p, B, Gmax, &parity, st));
+        launches += 2 + (long long)batch * (4 + 2 * kmax);
+    }
+    HIPCHK(hipEventRecord(s0->ev1, st));
+    HIPCHK(hipStreamSynchronize(st));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, s0->ev0, s0->ev1));
+    for (int i = 0; i < B; i++) {
+        SegSolver *s = ss[i];
+        s->hst = hs[i]; s->parity = parity; s->rec_cols = 0; s->xi_valid = false;
+        if (energies) energies[i] = (int)(s->hst.cur_obj + s->c);     // :1379
+    }
+    s0->kernel_ms += ms; s0->launches += launches;
+    devs.release(); dstates.release();
     return LPBOX_OK;
 }
 

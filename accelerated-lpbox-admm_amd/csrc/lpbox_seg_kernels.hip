@@ -90,7 +90,7 @@ __device__ __forceinline__ double tm_row(const SegDev &d, int i, GET get) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(T) seg_k_init(SegDev d, double c1) {      // ADMM_bqp_unconstrained_init SEGcpp:658-810
+__device__ __forceinline__ void seg_b_init(const SegDev &d, double c1) {      // ADMM_bqp_unconstrained_init SEGcpp:658-810
     for (int s = 0; s < d.EPT; s++) {
         const int i = blockIdx.x * (T * d.EPT) + s * T + threadIdx.x;
         if (i >= d.n) continue;
@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(T) seg_k_init(SegDev d, double c1) {      // A
     }
 }
 
-__global__ void seg_k_set_window(SegDev d, int in, int out, int iter_start, int iter_end, int mode) {
+__device__ __forceinline__ void seg_b_set_window(const SegDev &d, int in, int out, int iter_start, int iter_end, int mode) {
     const int l2f = mode & 1;
     d.st[out] = d.st[in];
     SegState *s = d.st + out;
@@ -122,7 +122,7 @@ __global__ void seg_k_set_window(SegDev d, int in, int out, int iter_start, int 
     if (s->halt != SEG_HALT_ALLFIXED) s->halt = SEG_HALT_NONE;
 }
 
-__global__ void seg_k_resume(SegDev d, int in, int out, int reset_pcg_max) {
+__device__ __forceinline__ void seg_b_resume(const SegDev &d, int in, int out, int reset_pcg_max) {
     d.st[out] = d.st[in];
     if (d.st[out].halt == SEG_HALT_PCG_MORE) d.st[out].halt = SEG_HALT_NONE;
     if (reset_pcg_max) d.st[out].pcg_max = 0;
@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(T) seg_k_fix(SegDev d, int in, int out, int n_
 }
 
 // prep: finalise the previous iteration (workgroup 0 only), then start the next one
-__global__ void __launch_bounds__(T) seg_k_prep(SegDev d, int in, int out, int do_prep) {
+__device__ __forceinline__ void seg_b_prep(const SegDev &d, int in, int out, int do_prep) {
     __shared__ double red[2 * RED_MAXV * RED_MAXW];
     int parity = 0;
     const SegState *si = d.st + in;
@@ -246,7 +246,7 @@ __global__ void __launch_bounds__(T) seg_k_prep(SegDev d, int in, int out, int d
     store_partials<1>(d, PH_A, pa, red, parity);
 }
 
-__global__ void __launch_bounds__(T) seg_k_yrhs(SegDev d, int in, int out) {
+__device__ __forceinline__ void seg_b_yrhs(const SegDev &d, int in, int out) {
     __shared__ double red[2 * RED_MAXV * RED_MAXW];
     int parity = 0;
     const SegState *si = d.st + in;
@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(T) seg_k_yrhs(SegDev d, int in, int out) {
     if (LEADER) { d.st[out] = *si; d.st[out].rhoUpdated = 0; d.st[out].dinv_stale = 0; }
 }
 
-__global__ void __launch_bounds__(T) seg_k_resid(SegDev d, int in, int out) {
+__device__ __forceinline__ void seg_b_resid(const SegDev &d, int in, int out) {
     __shared__ double red[2 * RED_MAXV * RED_MAXW];
     int parity = 0;
     const SegState *si = d.st + in;
@@ -301,7 +301,7 @@ __global__ void __launch_bounds__(T) seg_k_resid(SegDev d, int in, int out) {
 }
 
 // tmp = M p with the search-direction update of the previous PCG iteration folded in
-__global__ void __launch_bounds__(T) seg_k_matvec(SegDev d, int in, int out) {
+__device__ __forceinline__ void seg_b_matvec(const SegDev &d, int in, int out) {
     __shared__ double red[2 * RED_MAXV * RED_MAXW];
     int parity = 0;
     const SegState *si = d.st + in;
@@ -366,7 +366,7 @@ __global__ void __launch_bounds__(T) seg_k_matvec(SegDev d, int in, int out) {
     store_partials<1>(d, PH_C, pc, red, parity);
 }
 
-__global__ void __launch_bounds__(T) seg_k_update(SegDev d, int in, int out) {
+__device__ __forceinline__ void seg_b_update(const SegDev &d, int in, int out) {
     __shared__ double red[2 * RED_MAXV * RED_MAXW];
     int parity = 0;
     const SegState *si = d.st + in;
@@ -395,7 +395,7 @@ __global__ void __launch_bounds__(T) seg_k_update(SegDev d, int in, int out) {
     if (LEADER) { d.st[out] = *si; d.st[out].pcg_k = pcg_k + 1; }
 }
 
-__global__ void __launch_bounds__(T) seg_k_post(SegDev d, int in, int out) {
+__device__ __forceinline__ void seg_b_post(const SegDev &d, int in, int out) {
     __shared__ double red[2 * RED_MAXV * RED_MAXW];
     int parity = 0;
     const SegState *si = d.st + in;
@@ -475,6 +475,30 @@ __global__ void seg_k_pack(SegDev d, const int *live_idx, int rows, int ws, doub
     }
 }
 
+
+__global__ void __launch_bounds__(T) seg_kb_init_c1(const SegDev *devs) { const SegDev &d = devs[blockIdx.y]; if ((int)blockIdx.x >= d.G) return; seg_b_init(d, d.c1_init); }
+__global__ void seg_kb_collect(const SegDev *devs, int parity, SegState *out) { out[blockIdx.x] = devs[blockIdx.x].st[parity]; }
+
+// entry points: one problem (descriptor by value) / a batch of problems in lockstep (descriptor array, blockIdx.y = problem;
+// workgroups beyond a problem's own count leave at once).  The bodies above use blockIdx.x only.
+__global__ void __launch_bounds__(T) seg_k_init(SegDev d, double c1) { seg_b_init(d, c1); }
+__global__ void __launch_bounds__(T) seg_kb_init(const SegDev *devs, double c1) { const SegDev &d = devs[blockIdx.y]; if ((int)blockIdx.x >= d.G) return; seg_b_init(d, c1); }
+__global__ void seg_k_set_window(SegDev d, int in, int out, int iter_start, int iter_end, int mode) { seg_b_set_window(d, in, out, iter_start, iter_end, mode); }
+__global__ void seg_kb_set_window(const SegDev *devs, int in, int out, int iter_start, int iter_end, int mode) { const SegDev &d = devs[blockIdx.y]; if ((int)blockIdx.x >= d.G) return; seg_b_set_window(d, in, out, iter_start, iter_end, mode); }
+__global__ void seg_k_resume(SegDev d, int in, int out, int reset_pcg_max) { seg_b_resume(d, in, out, reset_pcg_max); }
+__global__ void seg_kb_resume(const SegDev *devs, int in, int out, int reset_pcg_max) { const SegDev &d = devs[blockIdx.y]; if ((int)blockIdx.x >= d.G) return; seg_b_resume(d, in, out, reset_pcg_max); }
+__global__ void __launch_bounds__(T) seg_k_prep(SegDev d, int in, int out, int do_prep) { seg_b_prep(d, in, out, do_prep); }
+__global__ void __launch_bounds__(T) seg_kb_prep(const SegDev *devs, int in, int out, int do_prep) { const SegDev &d = devs[blockIdx.y]; if ((int)blockIdx.x >= d.G) return; seg_b_prep(d, in, out, do_prep); }
+__global__ void __launch_bounds__(T) seg_k_yrhs(SegDev d, int in, int out) { seg_b_yrhs(d, in, out); }
+__global__ void __launch_bounds__(T) seg_kb_yrhs(const SegDev *devs, int in, int out) { const SegDev &d = devs[blockIdx.y]; if ((int)blockIdx.x >= d.G) return; seg_b_yrhs(d, in, out); }
+__global__ void __launch_bounds__(T) seg_k_resid(SegDev d, int in, int out) { seg_b_resid(d, in, out); }
+__global__ void __launch_bounds__(T) seg_kb_resid(const SegDev *devs, int in, int out) { const SegDev &d = devs[blockIdx.y]; if ((int)blockIdx.x >= d.G) return; seg_b_resid(d, in, out); }
+__global__ void __launch_bounds__(T) seg_k_matvec(SegDev d, int in, int out) { seg_b_matvec(d, in, out); }
+__global__ void __launch_bounds__(T) seg_kb_matvec(const SegDev *devs, int in, int out) { const SegDev &d = devs[blockIdx.y]; if ((int)blockIdx.x >= d.G) return; seg_b_matvec(d, in, out); }
+__global__ void __launch_bounds__(T) seg_k_update(SegDev d, int in, int out) { seg_b_update(d, in, out); }
+__global__ void __launch_bounds__(T) seg_kb_update(const SegDev *devs, int in, int out) { const SegDev &d = devs[blockIdx.y]; if ((int)blockIdx.x >= d.G) return; seg_b_update(d, in, out); }
+__global__ void __launch_bounds__(T) seg_k_post(SegDev d, int in, int out) { seg_b_post(d, in, out); }
+__global__ void __launch_bounds__(T) seg_kb_post(const SegDev *devs, int in, int out) { const SegDev &d = devs[blockIdx.y]; if ((int)blockIdx.x >= d.G) return; seg_b_post(d, in, out); }
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -533,5 +557,52 @@ hipError_t seg_enqueue_finalize(const SegDev &d, int *parity, hipStream_t s) {
 
 hipError_t seg_launch_pack_xiters(const SegDev &d, const int *live_idx, int rows, int ws, double *out, hipStream_t s) {
     hipLaunchKernelGGL(seg_k_pack, dim3(256), dim3(256), 0, s, d, live_idx, rows, ws, out);
+    return hipGetLastError();
+}
+
+// ---- the same launch sequences for a batch of problems (devs: device array of descriptors; grid = (largest workgroup count, problems)) ----
+#define SEG_LAUNCH_B(kernel, gx, ...)                                                                          \
+    do {                                                                                                       \
+        hipLaunchKernelGGL(kernel, dim3(gx, B), dim3(T), 0, s, devs, *parity, *parity ^ 1, ##__VA_ARGS__);      \
+        *parity ^= 1;                                                                                          \
+    } while (0)
+
+hipError_t segb_launch_init(const SegDev *devs, int B, int Gmax, hipStream_t s) {
+    hipLaunchKernelGGL(seg_kb_init_c1, dim3(Gmax, B), dim3(T), 0, s, devs);
+    return hipGetLastError();
+}
+hipError_t segb_launch_set_window(const SegDev *devs, int B, int iter_start, int iter_end, int mode, int *parity, hipStream_t s) {
+    hipLaunchKernelGGL(seg_kb_set_window, dim3(1, B), dim3(1), 0, s, devs, *parity, *parity ^ 1, iter_start, iter_end, mode);
+    *parity ^= 1;
+    return hipGetLastError();
+}
+hipError_t segb_launch_copy(const SegDev *devs, int B, int reset_pcg_max, int *parity, hipStream_t s) {
+    hipLaunchKernelGGL(seg_kb_resume, dim3(1, B), dim3(1), 0, s, devs, *parity, *parity ^ 1, reset_pcg_max);
+    *parity ^= 1;
+    return hipGetLastError();
+}
+hipError_t segb_enqueue_iterations(const SegDev *devs, int B, int Gmax, int iters, int kmax, int *parity, hipStream_t s) {
+    for (int it = 0; it < iters; it++) {
+        SEG_LAUNCH_B(seg_kb_prep, Gmax, 1);
+        SEG_LAUNCH_B(seg_kb_yrhs, Gmax);
+        SEG_LAUNCH_B(seg_kb_resid, Gmax);
+        for (int k = 0; k < kmax; k++) { SEG_LAUNCH_B(seg_kb_matvec, Gmax); SEG_LAUNCH_B(seg_kb_update, Gmax); }
+        SEG_LAUNCH_B(seg_kb_post, Gmax);
+    }
+    return hipGetLastError();
+}
+hipError_t segb_enqueue_pcg_more(const SegDev *devs, int B, int Gmax, int pairs, int *parity, hipStream_t s) {
+    hipLaunchKernelGGL(seg_kb_resume, dim3(1, B), dim3(1), 0, s, devs, *parity, *parity ^ 1, 0);
+    *parity ^= 1;
+    for (int k = 0; k < pairs; k++) { SEG_LAUNCH_B(seg_kb_matvec, Gmax); SEG_LAUNCH_B(seg_kb_update, Gmax); }
+    SEG_LAUNCH_B(seg_kb_post, Gmax);
+    return hipGetLastError();
+}
+hipError_t segb_enqueue_finalize(const SegDev *devs, int B, int Gmax, int *parity, hipStream_t s) {
+    SEG_LAUNCH_B(seg_kb_prep, Gmax, 0);
+    return hipGetLastError();
+}
+hipError_t segb_collect_states(const SegDev *devs, int B, int parity, SegState *out, hipStream_t s) {
+    hipLaunchKernelGGL(seg_kb_collect, dim3(B), dim3(1), 0, s, devs, parity, out);
     return hipGetLastError();
 }

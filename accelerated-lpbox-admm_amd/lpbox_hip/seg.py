@@ -223,3 +223,23 @@ class PyLPboxADMMsolver:
         v = C.c_double()
         check(self._L.lpbox_debug_get_scalar(self._h, 0, name.encode(), C.byref(v)), "lpbox_debug_get_scalar")
         return v.value
+
+
+def solve_batch(solvers):
+    """solve_init() + solve_iter() for a list of segmentation solvers (each holding its image / problem) advanced in lockstep by ONE
+    launch chain on the GPU (C-ABI lpbox_seg_legacy_batch) -- the reference's own workload, image_segmentation.cpp:24-29: images
+    0..99 at 1e4 nodes, where one solve at a time leaves the GPU idle.  Every problem keeps its own control state, so each result is
+    bit-identical to solver.solve_init(); solver.solve_iter().  Returns the list of int energies; afterwards every solver answers
+    get_obj() / get_x_sol() / counters() as after its own solve.  (The per-solve result files are not written here.)"""
+    solvers = list(solvers)
+    if not solvers:
+        return []
+    for s in solvers:
+        if not s._have_problem:
+            root = s.data_root or os.environ.get("LPBOX_SEG_DATA_ROOT") or "../data"
+            s.set_image(load_gray(os.path.join(root, f"{s.problem}.jpg")))
+    L = solvers[0]._L
+    hs = (C.c_void_p * len(solvers))(*[s._h for s in solvers])
+    en = (C.c_int * len(solvers))()
+    check(L.lpbox_seg_legacy_batch(hs, len(solvers), en), "lpbox_seg_legacy_batch")
+    return [int(v) for v in en]

@@ -129,6 +129,11 @@ int lpbox_set_problem_bqp(lpbox_t *h, int n, int nnz, const int *rowptr, const i
 int lpbox_seg_set_image(lpbox_t *h, const unsigned char *gray, int rows, int cols, int num_nodes);
 /* SEG pxd:10 `int ADMM_bqp_unconstrained_legacy()` (SEGcpp:1200-1380): *energy = int(cur_obj + c). */
 int lpbox_seg_legacy(lpbox_t *h, int *energy);
+/* solve_init + solve_iter for `count` segmentation handles (each after lpbox_seg_set_image / lpbox_set_problem_bqp) advanced in lockstep by
+ * ONE launch chain -- the workload of image_segmentation.cpp:24-29 (images 0..99 at 1e4 nodes), where a single solve is launch-bound.
+ * Per problem the arithmetic is that of lpbox_init + lpbox_seg_legacy on its own (own control state, sums, iteration counts); afterwards
+ * every handle answers its getters as usual.  energies[count]. */
+int lpbox_seg_legacy_batch(lpbox_t **handles, int count, int *energies);
 /* SEG pxd:15 `double get_final_obj()` (SEGcpp:868-893): energy of the assembled rounded solution on the ORIGINAL A, b, plus c. */
 int lpbox_seg_get_obj(lpbox_t *h, double *out);
 int lpbox_seg_get_shape(lpbox_t *h, int *rows, int *cols);   /* scaled_row, scaled_col (SEGcpp:716-717), for save_img */

@@ -93,3 +93,35 @@ def test_full_resolution_image_windows_bit_exact():
         assert g.solve_iter_l2f(w * 10, (w + 1) * 10, vec, 0) == o.solve_iter_l2f(w * 10, (w + 1) * 10, vec, 0)
         assert bits_equal(g.get_x_iters_2d(10), o.get_x_iters_2d(10)), f"window {w}"
     compare_state(g, o, "full-res")
+
+
+def test_batched_legacy_solves_equal_individual_solves():
+    """lpbox_seg_legacy_batch: several problems of DIFFERENT sizes advanced in lockstep by one launch chain; each must come out
+    bit-identical to its own solve_init() + solve_iter() (own control state, own PCG / outer iteration counts, own stop)."""
+    from lpbox_hip.seg import PyLPboxADMMsolver, load_gray, solve_batch
+
+    def gray(name):
+        return load_gray(os.path.join(GOLDEN, "seg", name))
+    imgs = [(gray("0.jpg"), 10000), (gray("7.jpg"), 2500), (gray("0.jpg")[40:300, 60:420], 6000), (gray("7.jpg"), 10000),
+            (gray("0.jpg")[:, ::-1].copy(), 4000)]
+
+    def make(k):
+        g, nodes = imgs[k]
+        s = PyLPboxADMMsolver(0, nodes, k)
+        s.write_files = False
+        s.set_image(g)
+        return s
+    single = [make(k) for k in range(len(imgs))]
+    ref = []
+    for s in single:
+        s.solve_init()
+        ref.append((s.solve_iter(), s.get_obj(), s.counters(), s.stop(), s.get_x_sol().copy(), s.debug_vec("x")))
+    batch = [make(k) for k in range(len(imgs))]
+    en = solve_batch(batch)
+    assert len({r[2] for r in ref}) > 1                       # the problems really take different iteration counts
+    for k, s in enumerate(batch):
+        assert en[k] == ref[k][0] and s.get_obj() == ref[k][1] and s.counters() == ref[k][2] and s.stop() == ref[k][3], k
+        assert np.array_equal(s.get_x_sol(), ref[k][4]) and bits_equal(s.debug_vec("x"), ref[k][5]), k
+    # a solver of the batch goes on working on its own afterwards
+    batch[1].solve_init()
+    assert batch[1].solve_iter() == ref[1][0]
