@@ -161,11 +161,11 @@ int finalize(lpbox_t *h) {
     int nmax = 0, lmax = 0, zmax = 0;
     for (auto &I : h->inst) { nmax = std::max(nmax, I.n); lmax = std::max(lmax, I.l); zmax = std::max(zmax, I.nnz); }
     if (nmax > 65534 || lmax > 65534) return fail(LPBOX_E_UNSUPPORTED, "n or l exceeds the uint16 index range of the on-chip kernel");
-    // workgroup geometry: 8 wavefronts (two per SIMD of the CU) with as few slots per thread as the instance allows; the
-    // largest instances use 4 wavefronts x 8 slots so that each lane may take the whole 512-entry register file.
+    // workgroup geometry: 8 wavefronts (two per SIMD of the CU) with as few slots per thread as the instance allows (1, 2 or 4; the
+    // 4-slot variant keeps the vectors the PCG loop never reads out of registers); beyond 2048 positions 4 wavefronts x 8 slots.
     // LPBOX_LP_THREADS overrides (tuning only).
     const int big = std::max(nmax, lmax);
-    int T = big > 1024 ? 256 : 512;       // n = 2000: 256 x 8 measured faster over a whole solve than 512 x 4 (both spill; LPBOX_LP_THREADS tries the other)
+    int T = 512;                          // 8 waves with short lists beat 4 waves with long ones also at n = 2000 (512 x 4, register-lean variant)
     if (const char *e = getenv("LPBOX_LP_THREADS")) { int v = atoi(e); if (v == 256 || v == 512 || v == 1024) T = v; }
     const int max_ept = T == 256 ? 8 : (T == 1024 ? 1 : 4);
     int EPT = 1;

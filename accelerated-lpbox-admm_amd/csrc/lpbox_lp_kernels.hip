@@ -46,13 +46,16 @@ namespace {
 // LDS carve-up shared by the launcher (size) and the kernel (pointers)
 // ------------------------------------------------------------------------------------------------
 struct LdsLayout {
-    size_t gx, gl, red, rs_ptr, cs_ptr, hs_ptr, rs_col, cs_row, total;
-    __host__ __device__ LdsLayout(int NS, int LS, int ZS) {
+    size_t gx, gl, red, hist, rowf, rowy3, rs_ptr, cs_ptr, hs_ptr, rs_col, cs_row, total;
+    __host__ __device__ LdsLayout(int NS, int LS, int ZS, bool lean) {
         size_t o = 0;
         auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 15) & ~size_t(15); return at; };
         gx = take(sizeof(double) * ((size_t)NS + 1));     // + zero slot at [NS]
         gl = take(sizeof(double) * 3 * ((size_t)LS + 1)); // three l-vectors interleaved: gl[3*i + c]; zero slot at i = LS
         red = take(sizeof(double) * 2 * RED_MAXV * RED_MAXW);
+        hist = take(sizeof(double) * 2 * LP_HIST);        // objective history, double-buffered (read by all, rewritten by thread 0)
+        rowf = take(lean ? sizeof(double) * ((size_t)LS + 1) : 0);     // multi-slot variants: f and y3 by row live here, not in registers
+        rowy3 = take(lean ? sizeof(double) * ((size_t)LS + 1) : 0);
         rs_ptr = take(sizeof(int) * ((size_t)NS + 1));
         cs_ptr = take(sizeof(int) * ((size_t)NS + 1));
         hs_ptr = take(sizeof(int) * ((size_t)NS + 1));
@@ -97,7 +100,13 @@ __device__ __forceinline__ void static_for(F &&f) {
 template <typename C>
 struct Lists {
     unsigned addr[C::total > 0 ? C::total : 1];   // LDS address of each gathered element, padded with the zero slot's address
-    int tail_begin[C::N], tail_end[C::N];         // entries beyond the register capacity: indices read from LDS
+    const int *ptr;                               // LDS copy of the list pointers (entries beyond the register capacity are re-read from there)
+    int pos0, pstride;                            // this thread's list of slot s is ptr[pos0 + s * pstride] .. ptr[pos0 + s * pstride + 1]
+    int tail_any[C::N];                           // wave-uniform: some lane of the wave has entries beyond the register capacity
+    // single/double-slot variants keep the tail bounds in registers (re-reading them costs the 512 x 1 kernel 3 %); the multi-slot
+    // variants, short of registers, re-read them from the LDS pointer arrays in the rare wave that has a tail
+    static constexpr bool TAILREG = C::N < 4;
+    int tail_begin[TAILREG ? C::N : 1], tail_end[TAILREG ? C::N : 1];
     int wlen[C::N];                               // wave-uniform number of register entries to walk
     unsigned base, zero;                          // address of element 0 / of the zero slot
 };
@@ -108,9 +117,9 @@ __device__ __forceinline__ void build_list(Lists<C> &g, int begin, int end, cons
     constexpr int CAP = C::at(S), OFF = C::off(S);
 #pragma unroll
     for (int k = 0; k < CAP; k++) g.addr[OFF + k] = (begin + k < end) ? g.base + STRIDE * (unsigned)idx[begin + k] : g.zero;
-    g.tail_begin[S] = begin + CAP < end ? begin + CAP : end;
-    g.tail_end[S] = end;
     const int len = end - begin;
+    g.tail_any[S] = wave_max_int(len > CAP ? 1 : 0);
+    if constexpr (Lists<C>::TAILREG) { g.tail_begin[S] = begin + CAP < end ? begin + CAP : end; g.tail_end[S] = end; }
     g.wlen[S] = wave_max_int(len < CAP ? len : CAP);
 }
 
@@ -183,10 +192,17 @@ __device__ __forceinline__ void gather_all(const Lists<C> &g, const uint16_t *id
     }
     static_for<N>([&](auto S) {                                         // long lists: indices from LDS
         constexpr int s = decltype(S)::value;
-        for (int k = g.tail_begin[s]; k < g.tail_end[s]; k += GCH) {
+        int tb = 0, te = 0;
+        if constexpr (Lists<C>::TAILREG) { tb = g.tail_begin[s]; te = g.tail_end[s]; }
+        else if (g.tail_any[s]) {                                       // rare: the list pointers come back from LDS, not from registers
+            const int lb = g.ptr[g.pos0 + s * g.pstride];
+            te = g.ptr[g.pos0 + s * g.pstride + 1];
+            tb = lb + C::at(s) < te ? lb + C::at(s) : te;
+        }
+        for (int k = tb; k < te; k += GCH) {
             unsigned o[GCH];
 #pragma unroll
-            for (int q = 0; q < GCH; q++) o[q] = (k + q < g.tail_end[s]) ? g.base + STRIDE * (unsigned)idx[k + q] : g.zero;
+            for (int q = 0; q < GCH; q++) o[q] = (k + q < te) ? g.base + STRIDE * (unsigned)idx[k + q] : g.zero;
             double v[GCH];
 #pragma unroll
             for (int q = 0; q < GCH; q++) v[q] = lds_ld<COMP>(o[q]);
@@ -232,10 +248,17 @@ __device__ __forceinline__ void gather_all2(const Lists<C> &g, const uint16_t *i
     });
     static_for<N>([&](auto S) {
         constexpr int s = decltype(S)::value;
-        for (int k = g.tail_begin[s]; k < g.tail_end[s]; k += GCH) {
+        int tb = 0, te = 0;
+        if constexpr (Lists<C>::TAILREG) { tb = g.tail_begin[s]; te = g.tail_end[s]; }
+        else if (g.tail_any[s]) {                                       // rare: the list pointers come back from LDS, not from registers
+            const int lb = g.ptr[g.pos0 + s * g.pstride];
+            te = g.ptr[g.pos0 + s * g.pstride + 1];
+            tb = lb + C::at(s) < te ? lb + C::at(s) : te;
+        }
+        for (int k = tb; k < te; k += GCH) {
             unsigned o[GCH];
 #pragma unroll
-            for (int q = 0; q < GCH; q++) o[q] = (k + q < g.tail_end[s]) ? g.base + STRIDE * (unsigned)idx[k + q] : g.zero;
+            for (int q = 0; q < GCH; q++) o[q] = (k + q < te) ? g.base + STRIDE * (unsigned)idx[k + q] : g.zero;
             double va[GCH], vb[GCH];
 #pragma unroll
             for (int q = 0; q < GCH; q++) { va[q] = lds_ld<CA>(o[q]); vb[q] = lds_ld<CB>(o[q]); }
@@ -299,6 +322,49 @@ __global__ void __launch_bounds__(T) lp_init_kernel(LpBatchDev bd, const double 
 //   T    threads per instance, EPT variable (and row) slots per thread,
 //   RCAPS / CCAPS  per-slot register capacities (Caps<...>) of the row-task / column gather lists.
 // ------------------------------------------------------------------------------------------------
+// a wave-uniform double moved to scalar registers (the compiler cannot prove uniformity of values that came out of an LDS reduction)
+__device__ __forceinline__ double uniform_f64(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
+// One value per slot of the thread, either in registers (N slots) or -- multi-slot variants, where the register file is the scarce
+// resource -- left in its HBM/L2 pool and touched at its few use sites per outer iteration (vectors the PCG loop never reads).
+// Every thread only ever touches its own elements, so no synchronisation is involved.
+template <bool MEM, int N, int STRIDE>
+struct SlotVec {
+    double r[MEM ? 1 : N];
+    double *g;                                   // this thread's element of slot 0; slot s is STRIDE elements further
+    __device__ __forceinline__ void load(double *base) {
+        g = base;
+        if constexpr (!MEM) {
+#pragma unroll
+            for (int s = 0; s < N; s++) r[s] = base[s * STRIDE];
+        }
+    }
+    __device__ __forceinline__ double get(int s) const { if constexpr (MEM) return g[s * STRIDE]; else return r[s]; }
+    __device__ __forceinline__ void set(int s, double v) { if constexpr (MEM) g[s * STRIDE] = v; else r[s] = v; }
+    __device__ __forceinline__ void store() const {
+        if constexpr (!MEM) {
+#pragma unroll
+            for (int s = 0; s < N; s++) g[s * STRIDE] = r[s];
+        }
+    }
+};
+
+// One value per row task of the thread (owned by the task's leader lane), in registers or -- multi-slot variants -- in an LDS vector
+// indexed like the gathered l-vectors (element idx at lds[idx * STRIDE]); only the leader lane ever touches its element.
+template <bool MEM, int N, int STRIDE>
+struct RowVec {
+    double r[MEM ? 1 : N];
+    double *lds;
+    __device__ __forceinline__ double get(int s, int idx, bool leader) const {
+        if constexpr (MEM) return leader ? lds[idx * STRIDE] : 0.0; else return r[s];
+    }
+    __device__ __forceinline__ void set(int s, int idx, bool leader, double v) {
+        if constexpr (MEM) { if (leader) lds[idx * STRIDE] = v; } else r[s] = v;
+    }
+};
+
 template <int T, int EPT, typename RCAPS, typename CCAPS, typename HCAPS>
 __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_start, int iter_end, int mode) {
     const int l2f = mode & 1, rec = mode & 2;     // rec: keep x after every iteration in xhist (x_iters of the l2f loop; print_fix_info 2/3 of the plain loop)
@@ -311,10 +377,11 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
     const int nnz = isc[NI_NNZ];
     const size_t on = (size_t)inst * bd.NS, ol = (size_t)inst * bd.LS, oz = (size_t)inst * bd.ZS;
 
-    const LdsLayout L(bd.NS, bd.LS, bd.ZS);
+    const LdsLayout L(bd.NS, bd.LS, bd.ZS, EPT >= 4);
     double *gx = (double *)(smem + L.gx);
     double *gl = (double *)(smem + L.gl);       // gl[3*i + c]: c = 0: q = E*p / f - y3, 1: z4, 2: E*y1
     double *red = (double *)(smem + L.red);
+    double *s_hist = (double *)(smem + L.hist);
     int *s_rs_ptr = (int *)(smem + L.rs_ptr);
     int *s_cs_ptr = (int *)(smem + L.cs_ptr);
     int *s_hs_ptr = (int *)(smem + L.hs_ptr);
@@ -333,30 +400,44 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
     }
 
     // ---- per-thread state ----
-    double x[EPT], z1[EPT], z2[EPT], b[EPT], pd[EPT], dinv[EPT], Esq[EPT];
-    bool live[EPT], valid[EPT];
-    double z4[EPT], f[EPT], Ex[EPT], y3[EPT];
-    bool rvalid[EPT];       // this lane is the LEADER (lane 0) of a row task: it owns the row's l-vector entries
-    bool rtask[EPT];        // this lane takes part in a row sum
-    int rrow[EPT];          // original row id of the row task in slot s
-    int rgl[EPT];           // storage index of that row in the gathered LDS l-vectors
-    int rG[EPT];            // lanes sharing that row (1,2,4,8)
+    constexpr bool LEAN = EPT >= 4;              // multi-slot variants: z1, z2, b, pd stay in memory, y1 / y2 are recomputed after the PCG
+    double x[EPT], dinv[EPT];
+    SlotVec<LEAN, EPT, T> z1, z2, b, pd;
+    z1.load(bd.z1 + on + tid); z2.load(bd.z2 + on + tid); b.load(bd.b + on + tid); pd.load(bd.pd + on + tid);
+    // Esq_diag_j = sum of squared entries of column j (LPcpp:2378-2390) = its length (entries are 1.0): needed only when the
+    // diagonal is rebuilt (iteration 0, a fix, a rho update), so it is re-read from the layout instead of living in a register
+    double Esq_reg[LEAN ? 1 : EPT];
+    if constexpr (!LEAN) {
+#pragma unroll
+        for (int s = 0; s < EPT; s++) Esq_reg[s] = (double)(bd.cmeta[on + s * T + tid] & 0x7FFF);
+    }
+    auto Esq = [&](int s) { if constexpr (LEAN) return (double)(bd.cmeta[on + s * T + tid] & 0x7FFF); else return Esq_reg[s]; };
+    bool live[EPT];
+    double Ex[EPT];
+    RowVec<LEAN, EPT, 3> z4;   // multi-slot variants: component 1 of the gathered l-vectors IS z4
+    RowVec<LEAN, EPT, 1> f, y3;
+    z4.lds = gl + 1; f.lds = (double *)(smem + L.rowf); y3.lds = (double *)(smem + L.rowy3);
+    // row task of slot s, packed: bits 0-15 storage index of the row in the gathered LDS l-vectors, 16-19 lanes sharing the row (1,2,4,8),
+    // bit 20 this lane is the LEADER (lane 0) of the task: it owns the row's l-vector entries
+    // (single-slot variants keep the three fields in registers of their own: the unpacking would sit in the PCG loop)
+    int rinfo[EPT], rGreg[LEAN ? 1 : EPT];
+    bool rvreg[LEAN ? 1 : EPT];
+    auto rgl = [&](int s) { return rinfo[s] & 0xFFFF; };
+    auto rG = [&](int s) { if constexpr (LEAN) return (rinfo[s] >> 16) & 15; else return rGreg[s]; };
+    auto rvalid = [&](int s) { if constexpr (LEAN) return (rinfo[s] & (1 << 20)) != 0; else return rvreg[s]; };
 #pragma unroll
     for (int s = 0; s < EPT; s++) {
         const int pos = s * T + tid;
-        valid[s] = true;    // every storage position exists; positions without a variable are never live
-        x[s] = bd.x[on + pos]; z1[s] = bd.z1[on + pos]; z2[s] = bd.z2[on + pos];
-        b[s] = bd.b[on + pos]; pd[s] = bd.pd[on + pos];
+        x[s] = bd.x[on + pos];
         live[s] = bd.live[on + pos] != 0;
         const int rid = bd.rid[on + pos], meta = bd.rmeta[on + pos];
-        rtask[s] = rid != 0xFFFF;
-        rvalid[s] = rtask[s] && (meta & 15) == 0;
-        rrow[s] = rtask[s] ? rid : 0;
-        rgl[s] = rtask[s] ? (int)bd.rgl[on + pos] : 0;
-        rG[s] = rtask[s] ? (meta >> 4) : 1;
-        z4[s] = f[s] = 0.0;
-        if (rvalid[s]) { z4[s] = bd.z4[ol + rrow[s]]; f[s] = bd.f[ol + rrow[s]]; }
-        Ex[s] = y3[s] = 0.0;
+        const bool rtask = rid != 0xFFFF, leader = rtask && (meta & 15) == 0;
+        rinfo[s] = rtask ? ((int)bd.rgl[on + pos] | ((meta >> 4) << 16) | (leader ? 1 << 20 : 0)) : (1 << 16);
+        if constexpr (!LEAN) { rinfo[s] &= 0xFFFF; rGreg[s] = rtask ? (meta >> 4) : 1; rvreg[s] = leader; }
+        z4.set(s, rgl(s), leader, leader ? bd.z4[ol + rid] : 0.0);
+        f.set(s, rgl(s), leader, leader ? bd.f[ol + rid] : 0.0);
+        y3.set(s, rgl(s), leader, 0.0);
+        Ex[s] = 0.0;
     }
     double rho1 = dsc[ND_RHO1], rho2 = dsc[ND_RHO2], rho4 = dsc[ND_RHO4];
     double prev_rho1 = dsc[ND_PREV_RHO1], prev_rho2 = dsc[ND_PREV_RHO2], prev_rho4 = dsc[ND_PREV_RHO4];
@@ -368,9 +449,16 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
     int n_live = isc[NI_NLIVE], rhoUpdated = isc[NI_RHO_UPDATED], hist_n = isc[NI_HIST_N];
     int pcg_total = isc[NI_PCG_TOTAL], outer_total = isc[NI_OUTER_TOTAL], last_pcg = isc[NI_LAST_PCG];
     int expr_ready = isc[NI_EXPR_READY];
-    double h[LP_HIST];
+    // the last LP_HIST objective values (compute_std_obj, LPcpp:459-469) live in LDS: every thread reads the window of the previous
+    // iteration from one buffer, thread 0 writes the new window into the other (no thread can still be reading that one: barriers of a
+    // whole iteration lie in between)
+    int hbuf = 0;
+    double h_reg[LEAN ? 1 : LP_HIST];            // single-slot variants have the registers to keep the window where it is used
+    if constexpr (LEAN) { if (tid < LP_HIST) s_hist[tid] = bd.hist[(size_t)inst * LP_HIST + tid]; }
+    else {
 #pragma unroll
-    for (int k = 0; k < LP_HIST; k++) h[k] = bd.hist[(size_t)inst * LP_HIST + k];
+        for (int k = 0; k < LP_HIST; k++) h_reg[k] = bd.hist[(size_t)inst * LP_HIST + k];
+    }
     const double learning_fact = LP_LEARNING_FACT;
     int ret = 0, stop = LP_STOP_NONE, parity = 0;
 
@@ -384,6 +472,8 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
     bool clong[EPT];             // this lane owns the quad's long column: its sum = own part + the quad's helper partials
     int anyhelp[EPT];            // wave-uniform: some quad of this wave splits a column
     rl.base = lds_addr(gx); rl.zero = lds_addr(gx + bd.NS);
+    rl.ptr = s_rs_ptr; cl.ptr = s_cs_ptr; hl.ptr = s_hs_ptr;
+    rl.pos0 = cl.pos0 = hl.pos0 = tid; rl.pstride = cl.pstride = hl.pstride = T;
     cl.base = lds_addr(gl); cl.zero = lds_addr(gl + 3 * bd.LS);
     hl.base = cl.base; hl.zero = cl.zero;
     int rGmax[EPT];              // wave-uniform largest lane group in the slot
@@ -391,13 +481,12 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
         constexpr int s = decltype(S)::value;
         const int pos = s * T + tid;
         build_list<RCAPS, s, 8>(rl, s_rs_ptr[pos], s_rs_ptr[pos + 1], s_rs_col);
-        rGmax[s] = wave_max_int(rG[s]);
+        rGmax[s] = wave_max_int(rG(s));
         build_list<CCAPS, s, 24>(cl, s_cs_ptr[pos], s_cs_ptr[pos + 1], s_cs_row);
         build_list<HCAPS, s, 24>(hl, s_hs_ptr[pos], s_hs_ptr[pos + 1], s_cs_row);
         const int cm = bd.cmeta[on + pos];
         clong[s] = (cm & 0x8000) != 0;
         anyhelp[s] = wave_max_int(s_hs_ptr[pos + 1] - s_hs_ptr[pos]) > 0;
-        Esq[s] = (double)(cm & 0x7FFF);   // Esq_diag_j = sum of squared entries of column j (LPcpp:2378-2390); entries are 1.0
     });
     auto op_add = [](double acc, double v) { return acc + v; };                 // res += 1.0 * v
     // out = (E * gx)_row for this thread's row tasks: the G lanes of a task add their interleaved share of the row in
@@ -409,9 +498,9 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
         static_for<EPT>([&](auto S) {
             constexpr int s = decltype(S)::value;
             double v = part[s];
-            if (rGmax[s] >= 2) { const double u = v + dpp_mov<0xB1>(v); v = rG[s] >= 2 ? u : v; }
-            if (rGmax[s] >= 4) { const double u = v + dpp_mov<0x4E>(v); v = rG[s] >= 4 ? u : v; }
-            if (rGmax[s] >= 8) { const double u = v + dpp_mov<0x141>(v); v = rG[s] >= 8 ? u : v; }
+            if (rGmax[s] >= 2) { const double u = v + dpp_mov<0xB1>(v); v = rG(s) >= 2 ? u : v; }
+            if (rGmax[s] >= 4) { const double u = v + dpp_mov<0x4E>(v); v = rG(s) >= 4 ? u : v; }
+            if (rGmax[s] >= 8) { const double u = v + dpp_mov<0x141>(v); v = rG(s) >= 8 ? u : v; }
             out[s] = v;
         });
     };
@@ -470,7 +559,7 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
             const int pos = s * T + tid;
             nf[s] = bd.newfix[on + pos];
             const double val = nf[s] == 2 ? 1.0 : 0.0;
-            part[0] = part[0] + (nf[s] ? b[s] * val : 0.0);     // fix_obj = b2.dot(x2), :1237
+            part[0] = part[0] + (nf[s] ? b.get(s) * val : 0.0);     // fix_obj = b2.dot(x2), :1237
             gx[pos] = nf[s] ? val : 0.0;
         }
         block_sum<T, 1>(part, red, parity);                      // (barrier inside also publishes gx)
@@ -484,7 +573,7 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
             rows_gather(cnt);                                         // E2*x2, :1276
 #pragma unroll
             for (int s = 0; s < EPT; s++) {
-                f[s] = f[s] - cnt[s];                                 // f1 = f - E2*x2, :1278
+                f.set(s, rgl(s), rvalid(s), f.get(s, rgl(s), rvalid(s)) - cnt[s]);      // f1 = f - E2*x2, :1278
                 if (nf[s]) { live[s] = false; x[s] = nf[s] == 2 ? 1.0 : 0.0; }
             }
             double px[1] = {0.0};
@@ -498,7 +587,7 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
             // update_expression (:1329 -> :2289-2404)
             dI = 0.0; dI += rho1 + rho2;
 #pragma unroll
-            for (int s = 0; s < EPT; s++) { pd[s] = dI; pd[s] += rho4 * Esq[s]; }
+            for (int s = 0; s < EPT; s++) { double v = dI; v += rho4 * Esq(s); pd.set(s, v); }
             r4Et = rho4;
             expr_ready = 1;
         }
@@ -509,11 +598,11 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
         // DiagonalPreconditioner state (LPcpp:883-890): always 1/pd as of the last compute; recomputed here so that a fix
         // applied while no rho update is pending (stale preconditioner = UB in the reference) is well defined.
 #pragma unroll
-        for (int s = 0; s < EPT; s++) dinv[s] = (pd[s] != 0.0) ? 1.0 / pd[s] : 1.0;
+        for (int s = 0; s < EPT; s++) { const double v = pd.get(s); dinv[s] = (v != 0.0) ? 1.0 / v : 1.0; }
         // E*x for the first iteration's y3
         __syncthreads();
 #pragma unroll
-        for (int s = 0; s < EPT; s++) if (valid[s]) gx[s * T + tid] = live[s] ? x[s] : 0.0;
+        for (int s = 0; s < EPT; s++) gx[s * T + tid] = live[s] ? x[s] : 0.0;
         __syncthreads();
         rows_gather(Ex);
 
@@ -526,33 +615,33 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
             double pn[1] = {0.0};
 #pragma unroll
             for (int s = 0; s < EPT; s++) {
-                const double t = x[s] + z1[s] / rho1;
+                const double t = x[s] + z1.get(s) / rho1;
                 y1[s] = t > 1 ? 1 : (t < 0 ? 0 : t);                  // project_box :409-421
-                const double u = (x[s] + z2[s] / rho2) - 0.5;         // project_shifted_Lp_ball :423-428
+                const double u = (x[s] + z2.get(s) / rho2) - 0.5;     // project_shifted_Lp_ball :423-428
                 y2[s] = u;
                 pn[0] = pn[0] + (live[s] ? u * u : 0.0);
             }
             block_sum<T, 1>(pn, red, parity);
-            {
-                const double c2 = 2 * sqrt(pn[0]);
+            const double c2 = 2 * sqrt(pn[0]);
 #pragma unroll
-                for (int s = 0; s < EPT; s++) y2[s] = y2[s] * c1 / c2 + 0.5;
-            }
+            for (int s = 0; s < EPT; s++) y2[s] = y2[s] * c1 / c2 + 0.5;
             STAMP(0)
             // ---------------- y3 = max(0, f - E x - z4/rho4), LPcpp:824-828 ----------------
 #pragma unroll
             for (int s = 0; s < EPT; s++) {
-                const double v = f[s] - Ex[s] - z4[s] / rho4;
-                y3[s] = v < 0 ? 0 : v;
-                if (rvalid[s]) { gl[3 * rgl[s]] = f[s] - y3[s]; gl[3 * rgl[s] + 1] = z4[s]; }
-                if (valid[s]) gx[s * T + tid] = live[s] ? y1[s] : 0.0;      // PCG start x0 = y1 (:892)
+                const double fs = f.get(s, rgl(s), rvalid(s)), z4s = z4.get(s, rgl(s), rvalid(s));
+                const double v = fs - Ex[s] - z4s / rho4;
+                const double y3s = v < 0 ? 0 : v;
+                y3.set(s, rgl(s), rvalid(s), y3s);
+                if (rvalid(s)) { gl[3 * rgl(s)] = fs - y3s; if constexpr (!LEAN) gl[3 * rgl(s) + 1] = z4s; }
+                gx[s * T + tid] = live[s] ? y1[s] : 0.0;      // PCG start x0 = y1 (:892)
             }
             __syncthreads();
             // ---------------- matrix-expression refresh, LPcpp:831-866 ----------------
             if (it == 0) {                                            // update_expression(0)
                 dI = 0.0; dI += rho1 + rho2;
 #pragma unroll
-                for (int s = 0; s < EPT; s++) { pd[s] = dI; pd[s] += rho4 * Esq[s]; }
+                for (int s = 0; s < EPT; s++) { double v = dI; v += rho4 * Esq(s); pd.set(s, v); }
                 r4Et = rho4;
                 expr_ready = 1;
             }
@@ -561,7 +650,7 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
                 const double inc4 = rcr * prev_rho4;
                 dI += inc;
 #pragma unroll
-                for (int s = 0; s < EPT; s++) { pd[s] += inc; pd[s] += inc4 * Esq[s]; }
+                for (int s = 0; s < EPT; s++) { double v = pd.get(s); v += inc; v += inc4 * Esq(s); pd.set(s, v); }
                 r4Et = learning_fact * r4Et;                          // rho4_E_transpose *= learning_fact (:864)
             }
             const double r4 = r4Et;
@@ -576,7 +665,7 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
 #pragma unroll
             for (int s = 0; s < EPT; s++) {
                 const double tA = tAs[s], tB = tBs[s];
-                double r_ = (rho1 * y1[s] + rho2 * y2[s]) - ((b[s] + z1[s]) + z2[s]);
+                double r_ = (rho1 * y1[s] + rho2 * y2[s]) - ((b.get(s) + z1.get(s)) + z2.get(s));
                 r_ += tA;
                 r_ -= tB;
                 rhs[s] = r_;
@@ -585,12 +674,12 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
                 double q[EPT];
                 rows_gather(q);
 #pragma unroll
-                for (int s = 0; s < EPT; s++) if (rvalid[s]) gl[3 * rgl[s] + 2] = q[s];
+                for (int s = 0; s < EPT; s++) if (rvalid(s)) gl[3 * rgl(s) + 2] = q[s];
             }
             __syncthreads();
             if (rhoUpdated) {                                         // DiagonalPreconditioner::compute (:883-890)
 #pragma unroll
-                for (int s = 0; s < EPT; s++) dinv[s] = (pd[s] != 0.0) ? 1.0 / pd[s] : 1.0;
+                for (int s = 0; s < EPT; s++) { const double v = pd.get(s); dinv[s] = (v != 0.0) ? 1.0 / v : 1.0; }
                 rhoUpdated = 0;
             }
             STAMP(1)
@@ -627,7 +716,7 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
                 if (!(residualNorm2 < threshold)) {                   // :284
                     while (k_it < LP_PCG_MAXITERS) {                  // :296
 #pragma unroll
-                        for (int s = 0; s < EPT; s++) if (valid[s]) gx[s * T + tid] = live[s] ? p[s] : 0.0;
+                        for (int s = 0; s < EPT; s++) gx[s * T + tid] = live[s] ? p[s] : 0.0;
                         __syncthreads();
                         STAMP(3)
                         {
@@ -639,7 +728,7 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
 #endif
                             STAMP(4)
 #pragma unroll
-                            for (int s = 0; s < EPT; s++) if (rvalid[s]) gl[3 * rgl[s]] = q[s];
+                            for (int s = 0; s < EPT; s++) if (rvalid(s)) gl[3 * rgl(s)] = q[s];
                         }
                         __syncthreads();
                         STAMP(5)
@@ -710,6 +799,15 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
             pcg_total += k_it;
             if (pcg_fail) stop = LP_STOP_PCG;
             if (pcg_fail && l2f) { ret = 1; break; }                  // :1450-1454: return 1, x_sol untouched
+            if constexpr (LEAN) {       // y1, y2 were not kept across the PCG: the same expressions on the same operands give the same bits
+#pragma unroll
+                for (int s = 0; s < EPT; s++) {
+                    const double t = x[s] + z1.get(s) / rho1;
+                    y1[s] = t > 1 ? 1 : (t < 0 ? 0 : t);
+                    const double u = (x[s] + z2.get(s) / rho2) - 0.5;
+                    y2[s] = u * c1 / c2 + 0.5;
+                }
+            }
             // ---------------- commit x: branchless predicated write (fixed variables keep their value) ----------------
 #pragma unroll
             for (int s = 0; s < EPT; s++) x[s] = live[s] ? xt[s] : x[s];
@@ -717,23 +815,23 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
             if (rec) {                                                // x_iters column cc (:1472-1475); plain loop: the xiter dump (:903-909)
                 double *xh = bd.xhist + ((size_t)inst * bd.ws_cap + cc) * bd.NS;
 #pragma unroll
-                for (int s = 0; s < EPT; s++) if (valid[s]) xh[s * T + tid] = x[s];
+                for (int s = 0; s < EPT; s++) xh[s * T + tid] = x[s];
                 cc++;
             }
             // ---------------- duals (:917-924 / :1487-1491) ----------------
             const double g1 = gamma_val * rho1, g2 = gamma_val * rho2, g4 = gamma_val * rho4;
 #pragma unroll
             for (int s = 0; s < EPT; s++) {
-                z1[s] = z1[s] + g1 * (x[s] - y1[s]);
-                z2[s] = z2[s] + g2 * (x[s] - y2[s]);
-                if (valid[s]) gx[s * T + tid] = live[s] ? x[s] : 0.0;
+                z1.set(s, z1.get(s) + g1 * (x[s] - y1[s]));
+                z2.set(s, z2.get(s) + g2 * (x[s] - y2[s]));
+                gx[s * T + tid] = live[s] ? x[s] : 0.0;
             }
             __syncthreads();
             rows_gather(Ex);                                          // E*x: feeds z4 now and y3 of the next iteration
 #pragma unroll
             for (int s = 0; s < EPT; s++) {
-                const double d = g4 * ((Ex[s] + y3[s]) - f[s]);
-                z4[s] = (!l2f && it == iter_start) ? d : z4[s] + d;   // :920-923 (plain loop overwrites on its first iteration)
+                const double d = g4 * ((Ex[s] + y3.get(s, rgl(s), rvalid(s))) - f.get(s, rgl(s), rvalid(s)));
+                z4.set(s, rgl(s), rvalid(s), (!l2f && it == iter_start) ? d : z4.get(s, rgl(s), rvalid(s)) + d);   // :920-923 (plain loop overwrites on its first iteration)
             }
             // ---------------- residual norms, objective (:931-1011) ----------------
             double p5[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
@@ -744,8 +842,8 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
                 p5[0] = p5[0] + (live[s] ? x[s] * x[s] : 0.0);
                 p5[1] = p5[1] + (live[s] ? d1 * d1 : 0.0);
                 p5[2] = p5[2] + (live[s] ? d2 * d2 : 0.0);
-                p5[3] = p5[3] + (live[s] ? b[s] * x[s] : 0.0);
-                p5[4] = p5[4] + (live[s] ? b[s] * xb : 0.0);
+                p5[3] = p5[3] + (live[s] ? b.get(s) * x[s] : 0.0);
+                p5[4] = p5[4] + (live[s] ? b.get(s) * xb : 0.0);
             }
             STAMP(12)
             block_sum<T, 5>(p5, red, parity);
@@ -773,6 +871,15 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
                 rcr = learning_fact - 1.0;
             }
             obj_val = p5[3];                                          // :972
+            double h[LP_HIST];
+            if constexpr (LEAN) {
+                const double *hs = s_hist + hbuf * LP_HIST;
+#pragma unroll
+                for (int k = 0; k < LP_HIST; k++) h[k] = hs[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < LP_HIST; k++) h[k] = h_reg[k];
+            }
             if (hist_n < LP_HIST) {
 #pragma unroll
                 for (int k = 0; k < LP_HIST; k++) if (k == hist_n) h[k] = obj_val;
@@ -780,6 +887,16 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
 #pragma unroll
                 for (int k = 0; k < LP_HIST - 1; k++) h[k] = h[k + 1];
                 h[LP_HIST - 1] = obj_val;
+            }
+            if constexpr (LEAN) {
+                hbuf ^= 1;
+                if (tid == 0) {
+#pragma unroll
+                    for (int k = 0; k < LP_HIST; k++) s_hist[hbuf * LP_HIST + k] = h[k];
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < LP_HIST; k++) h_reg[k] = h[k];
             }
             if (hist_n < 0x3fffffff) hist_n++;
             if (hist_n >= LP_HIST) {                                  // compute_std_obj :459-469, std_dev :358-377
@@ -797,20 +914,28 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
             if (std_obj <= LP_STD_THRESHOLD) { ret = 1; stop = LP_STOP_OBJSTD; break; }   // :977
             cur_obj = p5[4];                                          // :1001-1003
             if (best_bin_obj >= cur_obj) best_bin_obj = cur_obj;
+            if constexpr (LEAN) {       // the scalar state is uniform: keep it out of the vector registers across the next iteration
+                rho1 = uniform_f64(rho1); rho2 = uniform_f64(rho2); rho4 = uniform_f64(rho4);
+                prev_rho1 = uniform_f64(prev_rho1); prev_rho2 = uniform_f64(prev_rho2); prev_rho4 = uniform_f64(prev_rho4);
+                gamma_val = uniform_f64(gamma_val); rcr = uniform_f64(rcr); dI = uniform_f64(dI); r4Et = uniform_f64(r4Et);
+                std_obj = uniform_f64(std_obj); cur_obj = uniform_f64(cur_obj); best_bin_obj = uniform_f64(best_bin_obj);
+                cvg1 = uniform_f64(cvg1); cvg2 = uniform_f64(cvg2); obj_val = uniform_f64(obj_val);
+            }
             STAMP(14)
         }
         STAMP_STORE
     }
 
     // ---- write the state back ----
+    z1.store(); z2.store(); pd.store();
 #pragma unroll
     for (int s = 0; s < EPT; s++) {
         const int pos = s * T + tid;
-        if (valid[s]) {
-            bd.x[on + pos] = x[s]; bd.z1[on + pos] = z1[s]; bd.z2[on + pos] = z2[s]; bd.pd[on + pos] = pd[s];
+        {
+            bd.x[on + pos] = x[s];
             bd.live[on + pos] = live[s] ? 1 : 0;
         }
-        if (rvalid[s]) { bd.z4[ol + rrow[s]] = z4[s]; bd.f[ol + rrow[s]] = f[s]; }
+        if (rvalid(s)) { const int rid = bd.rid[on + pos]; bd.z4[ol + rid] = z4.get(s, rgl(s), true); bd.f[ol + rid] = f.get(s, rgl(s), true); }
     }
     if (tid == 0) {
         dsc[ND_RHO1] = rho1; dsc[ND_RHO2] = rho2; dsc[ND_RHO4] = rho4;
@@ -826,8 +951,7 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
         isc[NI_EXPR_READY] = expr_ready;
         if (l2f) isc[NI_ITER] = it;                                   // member `iter` (LPh:279), advanced by l2f only
         else isc[NI_PLAIN_ITER_P1] = it + 1;                          // LPcpp:1081
-#pragma unroll
-        for (int k = 0; k < LP_HIST; k++) bd.hist[(size_t)inst * LP_HIST + k] = h[k];
+        for (int k = 0; k < LP_HIST; k++) bd.hist[(size_t)inst * LP_HIST + k] = LEAN ? s_hist[hbuf * LP_HIST + k] : h_reg[LEAN ? 0 : k];
     }
 }
 
@@ -853,8 +977,7 @@ __global__ void lp_pack_xiters_kernel(LpBatchDev bd, const int *live_pos, const 
 // launchers
 // ------------------------------------------------------------------------------------------------
 size_t lp_window_lds_bytes(int T, int NS, int LS, int ZS) {
-    (void)T;
-    return LdsLayout(NS, LS, ZS).total;
+    return LdsLayout(NS, LS, ZS, NS / T >= 4).total;
 }
 
 // (threads, slots per thread) -> per-slot register capacities of the row-task / column gather lists.
