@@ -312,8 +312,9 @@ int lpbox_big_set_problem(lpbox_big_t *h, long n_glob, int c0, int n_loc, int l,
     if (n_glob <= 0 || n_loc <= 0 || l <= 0 || c0 < 0 || (long)c0 + n_loc > n_glob || !colptr || !b || colptr[0] != 0)
         return lpbox_fail(LPBOX_E_BADARG, "bad problem arguments");
     const int nnz = colptr[n_loc];
+    if (nnz < 0 || (nnz > 0 && !rowidx)) return lpbox_fail(LPBOX_E_BADARG, "row indices missing");
     for (int j = 0; j < n_loc; j++) {
-        if (colptr[j + 1] < colptr[j]) return lpbox_fail(LPBOX_E_BADARG, "colptr not monotone");
+        if (colptr[j] < 0 || colptr[j + 1] < colptr[j] || colptr[j + 1] > nnz) return lpbox_fail(LPBOX_E_BADARG, "colptr not monotone inside [0, nnz]");
         for (int k = colptr[j]; k < colptr[j + 1]; k++) {
             if (rowidx[k] < 0 || rowidx[k] >= l) return lpbox_fail(LPBOX_E_BADARG, "row index out of range");
             if (k > colptr[j] && rowidx[k] <= rowidx[k - 1]) return lpbox_fail(LPBOX_E_BADARG, "row indices must ascend inside a column");

@@ -486,12 +486,9 @@ int set_instance(lpbox_t *h, int idx, int n, int l, int nnz, const int *colptr, 
     if (n <= 0 || l <= 0 || nnz < 0 || !colptr || (!rowidx && nnz) || !b) return fail(LPBOX_E_BADARG, "bad problem arguments");
     if (n == l) return fail(LPBOX_E_UNSUPPORTED, "n == l: the reference's aliased sparse product is ill-defined here (LPcpp:103-107,150)");
     if (colptr[0] != 0 || colptr[n] != nnz) return fail(LPBOX_E_BADARG, "colptr does not span nnz");
-    LpInstance &I = h->inst[idx];
-    I.n = n; I.l = l; I.nnz = nnz;
-    I.colptr.assign(colptr, colptr + n + 1);
-    I.rowidx.assign(rowidx, rowidx + nnz);
+    // validate everything BEFORE touching the instance (a rejected call leaves it as it was) and before reading rowidx / vals through colptr
     for (int j = 0; j < n; j++) {
-        if (colptr[j + 1] < colptr[j]) return fail(LPBOX_E_BADARG, "colptr not monotone");
+        if (colptr[j] < 0 || colptr[j + 1] < colptr[j] || colptr[j + 1] > nnz) return fail(LPBOX_E_BADARG, "colptr not monotone inside [0, nnz]");
         for (int k = colptr[j]; k < colptr[j + 1]; k++) {
             if (rowidx[k] < 0 || rowidx[k] >= l) return fail(LPBOX_E_BADARG, "row index out of range");
             if (k > colptr[j] && rowidx[k] <= rowidx[k - 1]) return fail(LPBOX_E_BADARG, "row indices must ascend inside a column");
@@ -499,6 +496,10 @@ int set_instance(lpbox_t *h, int idx, int n, int l, int nnz, const int *colptr, 
                 return fail(LPBOX_E_UNSUPPORTED, "E has a stored value %g != 1; the LP kernels hold E implicitly as a 0/1 pattern", vals[k]);
         }
     }
+    LpInstance &I = h->inst[idx];
+    I.n = n; I.l = l; I.nnz = nnz;
+    I.colptr.assign(colptr, colptr + n + 1);
+    I.rowidx.assign(rowidx, rowidx + nnz);
     // CSR of E: rows in ascending column order (the order Eigen's column-major product accumulates a row in)
     I.rowptr.assign(l + 1, 0);
     for (int k = 0; k < nnz; k++) I.rowptr[rowidx[k] + 1]++;

@@ -485,7 +485,7 @@ int segc_l2f(SegSolver *s, int iter_start, int iter_end, const double *vec, int 
         HIPCHK(hipStreamSynchronize(s->stream));
         HIPCHK(s->xhist.alloc((size_t)SEG_XITERS_COLS * s->n)); s->ws_cap = SEG_XITERS_COLS; drop_graphs(s);
     }
-    if (ws > 0) HIPCHK(hipMemsetAsync(s->xhist.p, 0, sizeof(double) * (size_t)ws * s->n, s->stream));   // columns [0, ws) of this window
+    if (s->ws_cap > 0 && s->xhist.p) HIPCHK(hipMemsetAsync(s->xhist.p, 0, sizeof(double) * (size_t)s->ws_cap * s->n, s->stream));   // x_iters = Zero (SEGcpp:924): ALL staged columns, also those of an earlier, longer window
     s->rec_cols = 0;
     if (!s->left_idx.empty()) HIPCHK(hipMemcpyAsync(s->d_left.p, s->left_idx.data(), sizeof(int) * s->left_idx.size(), hipMemcpyHostToDevice, s->stream));
     rc = run_window(s, iter_end);

@@ -471,7 +471,7 @@ __global__ void seg_k_pack(SegDev d, const int *live_idx, int rows, int ws, doub
     const long total = (long)rows * ws;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const int r = (int)(e / ws), c = (int)(e % ws);
-        out[e] = d.xhist[(size_t)c * d.n + live_idx[r]];
+        out[e] = c < d.ws_cap ? d.xhist[(size_t)c * d.n + live_idx[r]] : 0.0;    // columns beyond the staged window: zeros, like the reference's matrix
     }
 }
 

@@ -135,3 +135,18 @@ def test_product_loop_on_the_big_path_matches_oracle_loop():
     ro = l2f.run_l2f(o, last, ws=100, max_iter=1500, col=P["n"])
     assert rg["objective"] == ro["objective"] and rg["windows"] == ro["windows"] and rg["fixed"] == ro["fixed"] > 0
     assert np.array_equal(g.local_x_sol(), o.get_x_sol().ravel())
+
+
+def test_alternating_window_lengths_leave_no_stale_columns():
+    """x_iters is re-created as zeros on every l2f call (LPcpp:1113): after a 30-iteration window, a 10-iteration window must
+    show zeros in columns 10..29, not the iterates of the longer window before."""
+    from lpbox_hip.big import BigLp
+    from lpbox_hip.synth import make_auction_like
+    P = make_auction_like(3000, 4)
+    g = BigLp(P)
+    g.solve_init()
+    o = _oracle(P, g)
+    for (a, b) in ((0, 30), (30, 40)):
+        assert g.solve_iter_l2f(a, b, None, 0) == o.solve_iter_l2f(a, b, np.zeros(P["n"]), 0)
+        assert bits_equal(g.get_x_iters_2d(30), o.get_x_iters_2d(30))
+    assert not g.get_x_iters_2d(30)[:, 10:].any()

@@ -58,6 +58,13 @@ def test_host_side_validation_and_no_cpu_fallback():
         b.set_problem(3, I["n"], I["l"], I["colptr"], I["rowidx"], I["b"])
     b.set_problem(0, I["n"], I["l"], I["colptr"], I["rowidx"], I["b"])
     assert b.get_org_n(0) == I["n"] and b.get_l(0) == I["l"]
+    # a malformed CSC (an interior colptr far beyond nnz) is rejected before rowidx is read through it, and a rejected call leaves
+    # the instance that was set before untouched
+    J = lp_instances("lp_20_60_seed0.npz")[1]
+    badp = J["colptr"].copy(); badp[1] = 10 ** 6
+    with pytest.raises(LpboxError, match="colptr"):
+        b.set_problem(0, J["n"], J["l"], badp, J["rowidx"], J["b"])
+    assert b.get_org_n(0) == I["n"] and b.get_l(0) == I["l"]
     with pytest.raises(LpboxError, match="solve_init"):
         b.solve_iter(0, 10)
     s = PyLPboxADMMsolver(0)

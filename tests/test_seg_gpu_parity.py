@@ -125,3 +125,13 @@ def test_batched_legacy_solves_equal_individual_solves():
     # a solver of the batch goes on working on its own afterwards
     batch[1].solve_init()
     assert batch[1].solve_iter() == ref[1][0]
+
+
+def test_alternating_window_lengths_leave_no_stale_columns():
+    """x_iters = Zero(n, 10) on every l2f call (SEGcpp:924): a 3-iteration window after a 10-iteration one shows zeros in columns 3..9."""
+    g, o = make_pair(2500, "7.jpg")
+    z = np.zeros(g.get_n())
+    for (a, b) in ((0, 10), (10, 13)):
+        assert g.solve_iter_l2f(a, b, z, 0) == o.solve_iter_l2f(a, b, z, 0)
+        assert bits_equal(g.get_x_iters_2d(10), o.get_x_iters_2d(10))
+    assert not g.get_x_iters_2d(10)[:, 3:].any()
