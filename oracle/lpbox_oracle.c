@@ -17,10 +17,12 @@
  * Build: gcc -O3 -ffp-contract=off (the reference's flags are plain -O3, LP/cython_solver/Makefile:9,34;
  * x86-64 baseline has no FMA so contraction never happens there either).
  */
+#define _POSIX_C_SOURCE 200809L   /* clock_gettime */
 #include "lpbox_oracle.h"
 
 #include <float.h>
 #include <math.h>
+#include <time.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -182,6 +184,7 @@ struct lpo {
     int *col_own, *col_help;       /* GPU order: split of the sum over column j of E (by ORIGINAL variable): own[j] leading entries,
                                       then chunks of help[4j+q] entries by quad lane q; NULL = unsplit */
     double *valT; int *curT;       /* scratch of spmv_Et */
+    FILE *log_fp;                  /* does_log (LPh:148, default ON in the reference): the per-iteration text log of ADMM_lp_iters */
     int *orgEr_ptr, *orgEr_col; double *orgEr_val;   /* CSR view of org_E (rows in ascending column order) */
     double *full_v;                /* scratch: a live vector expanded to the original variable order */
     int has_problem, inited;
@@ -293,6 +296,7 @@ void lpo_destroy(lpo_t *o) {
     if (!o) return;
     free_state(o);
     csc_free(&o->E); csc_free(&o->orgE); csc_free(&o->Et); csc_free(&o->r4Et);
+    if (o->log_fp) fclose(o->log_fp);
     free(o->b); free(o->f); free(o->gpu_pos); free(o->row_G); free(o->col_own); free(o->col_help); free(o->valT); free(o->curT);
     free(o->orgEr_ptr); free(o->orgEr_col); free(o->orgEr_val);
     free(o);
@@ -855,14 +859,49 @@ static int admm_iteration(lpo_t *o, int iter, int iter_start, int l2f, int *ret,
     return 0;
 }
 
-/* ADMM_lp_iters LPcpp:766-1095 (file logging LPcpp:1013-1067 not reproduced: it does not feed back) */
+/* the reference's per-iteration log block (LPcpp:1013-1067; `does_log`, LPh:148, is ON by default and not switchable from the pyx):
+ * six vector norms that nothing else needs + ten fprintf.  It does not feed back into the iteration; the oracle writes it only on
+ * request (lpo_set_log) so that the cost of what ./test really does can be timed beside the bare solve. */
+static double norm_eigen(const double *a, int n, double *scratch) {
+    for (int i = 0; i < n; i++) scratch[i] = a[i] * a[i];
+    return sqrt(redux_sum_eigen(scratch, n));
+}
+static void log_iteration(lpo_t *o, int iter, double secs) {
+    double *t = o->temp_mm;
+    FILE *fp = o->log_fp;
+    fprintf(fp, "norm of x_sol: %.9lf\n", norm_eigen(o->x, o->n, t));
+    fprintf(fp, "norm of y1: %.9lf\n", norm_eigen(o->y1, o->n, t));
+    fprintf(fp, "norm of y2: %.9lf\n", norm_eigen(o->y2, o->n, t));
+    fprintf(fp, "norm of y3: %.9lf\n", norm_eigen(o->y3, o->l, t));
+    fprintf(fp, "norm of z1: %.9lf\n", norm_eigen(o->z1, o->n, t));
+    fprintf(fp, "norm of z2: %.9lf\n", norm_eigen(o->z2, o->n, t));
+    fprintf(fp, "For z4\nnorm of z4: %.9lf\n", norm_eigen(o->z4, o->l, t));
+    fprintf(fp, "LongkangIter: %d;  x_sol: %lf; dou_obj:%lf; bin_obj: %lf\n", iter + 1, norm_eigen(o->x, o->n, t), o->obj_val, o->cur_obj);
+    fprintf(fp, "Time elapsed: %lfs\n", secs);
+    fprintf(fp, "-------------------------------------------------\n");
+}
+int lpo_set_log(lpo_t *o, const char *path) {
+    if (o->log_fp) { fclose(o->log_fp); o->log_fp = NULL; }
+    if (path && *path) { o->log_fp = fopen(path, "a+"); if (!o->log_fp) return -1; }     /* "a+" as LPcpp:772 */
+    return 0;
+}
+
+/* ADMM_lp_iters LPcpp:766-1095 */
 int lpo_iters(lpo_t *o, int iter_start, int iter_end) {
     if (!o->inited) return -1;
     int ret = 0, iter, cc = 0;
     o->trace_n = 0; o->last_stop = 0;
+    struct timespec t0, t1;
+    if (o->log_fp) clock_gettime(CLOCK_MONOTONIC, &t0);
     for (iter = iter_start; iter < iter_end; iter++) {
+        if (o->log_fp) fprintf(o->log_fp, "Iteration: %d\n", iter);                       /* :789 */
         int rc = admm_iteration(o, iter, iter_start, 0, &ret, &cc);
         if (rc) break;
+        if (o->log_fp) {
+            fprintf(o->log_fp, "Conjugate gradient stops after %d iterations\n", o->last_pcg_iters);   /* :898-901 */
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            log_iteration(o, iter, (double)((long)((t1.tv_sec - t0.tv_sec) * 1000 + (t1.tv_nsec - t0.tv_nsec) / 1000000)) / 1000.0);
+        }
     }
     o->last_plain_iter_plus1 = iter + 1;   /* :1081 */
     return ret;

@@ -52,6 +52,8 @@ void lpo_set_col_split(lpo_t *o, const int *own, const int *help4, int n);
 void lpo_set_chunk(lpo_t *o, int chunk);
 /* GPU order of the variable-sharded run: `ranks` contiguous blocks of variables; per-rank sums added in rank order (needs lpo_set_chunk) */
 void lpo_set_ranks(lpo_t *o, int ranks);
+/* the reference's default per-iteration text log (does_log, LPh:148; LPcpp:1013-1067) appended to `path`; NULL / "" turns it off (the default here) */
+int lpo_set_log(lpo_t *o, const char *path);
 /* 1 = print the reference's stop messages to stdout (default 0 = quiet). */
 void lpo_set_verbose(lpo_t *o, int verbose);
 

@@ -44,6 +44,7 @@ def lib():
     L.lpo_set_verbose.argtypes = [C.c_void_p, C.c_int]
     L.lpo_set_chunk.argtypes = [C.c_void_p, C.c_int]
     L.lpo_set_ranks.argtypes = [C.c_void_p, C.c_int]
+    L.lpo_set_log.argtypes = [C.c_void_p, C.c_char_p]
     L.lpo_set_positions.argtypes = [C.c_void_p, _ip, C.c_int, C.c_int]
     L.lpo_set_row_split.argtypes = [C.c_void_p, _ip, C.c_int]
     L.lpo_set_col_split.argtypes = [C.c_void_p, _ip, _ip, C.c_int]
@@ -107,6 +108,11 @@ class LpOracle:
                 self.h = None
         except Exception:
             pass
+
+    def set_log(self, path):
+        """The reference's default per-iteration log file (does_log); None turns it off."""
+        if self.L.lpo_set_log(self.h, os.fsencode(path) if path else None):
+            raise OSError(f"cannot open {path}")
 
     # -- problem input --
     def set_problem(self, n, l, colptr, rowidx, b, f=None, vals=None):
