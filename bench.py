@@ -176,7 +176,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="instances per GPU (configs 2 and 4)")
     ap.add_argument("--cpu-sample", type=int, default=None, help="instances solved by ONE CPU thread for cpu_baseline (0 = skip)")
     ap.add_argument("--cpu-pool", type=int, default=None, help="instances solved by the all-cores CPU pass")
-    ap.add_argument("--n", type=float, default=1e6, help="variables of the config 5 instance")
+    ap.add_argument("--variables", type=float, default=1e6, help="variables of the config 5 instance")
     args = ap.parse_args()
     rank, local_rank, world = dist_setup(args)
     if args.steps is None:
@@ -411,7 +411,7 @@ def run_big(args, rank, local_rank, world):
     local_rank, sync, allred, backend = gpu_dist_init(local_rank, world)
     from lpbox_hip.big import BigLp
     from lpbox_hip.synth import make_auction_like
-    n = int(args.n)
+    n = int(args.variables)
     P = make_auction_like(n, 0)
     g = BigLp(P, rank=rank, world=world, device=local_rank, use_torch_stream=True)
     window = 100
@@ -423,6 +423,7 @@ def run_big(args, rank, local_rank, world):
     for _ in range(args.warmup):
         step()
     sync()
+    c0, l0 = g.scalar("collectives"), g.scalar("launches")          # host-side counters, cumulative since the handle was created
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -430,7 +431,9 @@ def run_big(args, rank, local_rank, world):
     dt = time.perf_counter() - t0
     t_max = allred(dt, "MAX")
     if rank == 0:
-        o, p = g.scalar("outer_total"), g.scalar("pcg_total")
+        o, p = g.scalar("outer_total"), g.scalar("pcg_total")        # of the last step
+        per_iter = 1.0 / (args.steps * max(o, 1))
+        coll_per_iter, launches_per_iter = (g.scalar("collectives") - c0) * per_iter, (g.scalar("launches") - l0) * per_iter
         nnz, l = len(P["rowidx"]), P["l"]
         mE, mEt = 12 * nnz + 4 * (l + 1), 12 * nnz + 4 * (n + 1)
         K = p / o
@@ -443,11 +446,11 @@ def run_big(args, rank, local_rank, world):
                 "config": {"workload": "one LP with n = %d variables, l = %d rows, nnz = %d, variable-sharded over %d rank(s); "
                                        "init + %d ADMM iterations = 1 step (BASELINE configs[4])" % (n, l, nnz, world, window),
                            "parallelism": f"variable-sharded x{world}",
-                           "collectives_per_outer_iteration": g.scalar("collectives") / max(o, 1)},
+                           "exchanges_per_outer_iteration": coll_per_iter},
                 "roofline": {"bound": "hbm", "achieved": b_iter / s_iter / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": b_iter / s_iter / 1e9 / HBM_PEAK_GBS / world, "traffic": None,
                              "kernel": "large-instance launch chain (big_k_*)", "algorithmic_bytes_per_iteration": b_iter,
-                             "launches_per_iteration": g.scalar("launches") / max(o, 1),
+                             "launches_per_iteration": launches_per_iter,
                              "note": "chain-level: algorithmic bytes of an outer iteration (SURVEY 8d) / time per iteration, divided by "
                                      "the number of GPUs; per-kernel stats in profiles/"},
                 "detail": {"pcg_per_outer": K, "ms_per_iteration": 1e3 * s_iter, "backend": backend if world > 1 else None}}
