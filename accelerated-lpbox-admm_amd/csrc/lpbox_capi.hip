@@ -173,7 +173,7 @@ int finalize(lpbox_t *h) {
     if ((long)T * EPT < big && T == 512) { T = 256; EPT = 1; while (EPT < 8 && (long)T * EPT < big) EPT *= 2; }
     if ((long)T * EPT < big)
         return fail(LPBOX_E_UNSUPPORTED, "instance with max(n,l)=%d exceeds the on-chip kernel's %d register slots", big, T * EPT);
-    h->colsplit = T == 512 || T == 1024;                                        // variants compiled with helper lists (LP_DISPATCH)
+    h->colsplit = T == 512 || T == 1024 || (T == 256 && EPT == 2);              // variants compiled with helper lists (LP_DISPATCH)
     h->T = T; h->EPT = EPT;
     h->NS = T * EPT;                       // storage positions / row-task slots per instance
     h->LS = (lmax + 31) & ~31; h->ZS = (zmax + 7) & ~7;     // LS: a whole number of 32-row bank classes

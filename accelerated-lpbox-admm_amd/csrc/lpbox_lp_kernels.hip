@@ -983,7 +983,7 @@ size_t lp_window_lds_bytes(int T, int NS, int LS, int ZS) {
 // (threads, slots per thread) -> per-slot register capacities of the row-task / column gather lists.
 #define LP_DISPATCH(KERNEL_CALL)                                                                                                          \
     if (T == 256 && EPT == 1) { KERNEL_CALL(256, 1, (Caps<12>), (Caps<12>), (Caps<8>)) }                                                     \
-    else if (T == 256 && EPT == 2) { KERNEL_CALL(256, 2, (Caps<12, 12>), (Caps<24, 8>), (Caps<0, 0>)) }                                      \
+    else if (T == 256 && EPT == 2) { KERNEL_CALL(256, 2, (Caps<12, 12>), (Caps<12, 8>), (Caps<8, 4>)) }                                       \
     else if (T == 256 && EPT == 4) { KERNEL_CALL(256, 4, (Caps<12, 12, 12, 12>), (Caps<24, 8, 8, 8>), (Caps<0, 0, 0, 0>)) }                  \
     else if (T == 256 && EPT == 8) { KERNEL_CALL(256, 8, (Caps<8, 8, 8, 8, 8, 8, 8, 8>), (Caps<8, 8, 8, 8, 4, 4, 4, 4>), (Caps<0, 0, 0, 0, 0, 0, 0, 0>)) } \
     else if (T == 512 && EPT == 1) { KERNEL_CALL(512, 1, (Caps<12>), (Caps<12>), (Caps<8>)) }                                                \

@@ -13,3 +13,6 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/pro
 LPBOX_BIG_NOGRAPH=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_big -o big -- python3 $R/bench.py --config 5 --steps 2 --warmup 1 --cpu-sample 0 > $O/prof_big.log 2>&1 &&
 LPBOX_SEG_NOGRAPH=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_seg -o seg -- python3 $R/bench.py --config 3 --steps 3 --warmup 1 --cpu-sample 0 > $O/prof_seg.log 2>&1
 echo "collect_profiles rc=$?"
+cd /tmp; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_segb -o segb -- python3 $R/tools/seg_batch_bench.py 100 10000 > $O/prof_segb.log 2>&1; echo "seg batch profile rc=$?"
+# gpurun copies back at most 64 MiB: the per-dispatch traces are not needed by tools/summarise_profiles.py
+find $O/prof_* -name "*_kernel_trace.csv" -size +2M -delete 2>/dev/null; true

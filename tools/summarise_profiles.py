@@ -23,6 +23,8 @@ def counter(path, name, kernel_substr):
 
 
 stats(os.path.join(O, "prof_bench", "bench_kernel_stats.csv"), os.path.join(P, rnd + "_kernel_stats.csv"))
+if os.path.exists(os.path.join(O, "prof_segb", "segb_kernel_stats.csv")):
+    stats(os.path.join(O, "prof_segb", "segb_kernel_stats.csv"), os.path.join(P, rnd + "_seg_batch_kernel_stats.csv"))
 if os.path.exists(os.path.join(O, "prof_c4", "c4_kernel_stats.csv")):
     stats(os.path.join(O, "prof_c4", "c4_kernel_stats.csv"), os.path.join(P, rnd + "_config4_kernel_stats.csv"))
 stats(os.path.join(O, "prof_policy", "policy_kernel_stats.csv"), os.path.join(P, rnd + "_policy_kernel_stats.csv"))
