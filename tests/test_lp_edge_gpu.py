@@ -3,7 +3,7 @@ column and an empty row, a single-variable-per-row instance; each against the or
 import numpy as np
 import pytest
 
-from helpers import bits_equal, lp_instances, oracle_for
+from helpers import bits_equal, lp_instances, oracle_for, oracle_like, scripted_fix_vec
 from lpbox_hip.lp import LpBatch
 
 pytestmark = pytest.mark.gpu
@@ -88,3 +88,30 @@ def test_handles_driven_from_different_threads():
     for k in range(len(groups)):
         assert out[k][1] == seq[k][1]
         assert all(bits_equal(a, b) for a, b in zip(out[k][0], seq[k][0]))
+
+
+@pytest.mark.parametrize("n,seed", [(800, 1), (1500, 2)])
+def test_two_and_four_slot_variants_bit_exact(n, seed):
+    """Instances between the benchmark sizes: n = 800 runs on the 512 x 2 kernel, n = 1500 on the register-lean 512 x 4 one, both with
+    long columns shared inside quads of lanes of a slot; iterates, state and an early-fixing window bit for bit against the oracle."""
+    from lpbox_hip.lp import PyLPboxADMMsolver
+    from lpbox_hip.synth import make_auction_like
+    P = make_auction_like(n, seed)
+    I = dict(n=P["n"], l=P["l"], colptr=P["colptr"], rowidx=P["rowidx"], b=P["b"])
+    g = PyLPboxADMMsolver(0)
+    g.set_problem(I["n"], I["l"], I["colptr"], I["rowidx"], I["b"])
+    g.solve_init()
+    cfg = g.batch.config()
+    assert (cfg["threads"], cfg["elems_per_thread"]) == ((512, 2) if n <= 1024 else (512, 4))
+    own, help4 = g.batch.col_split(0)
+    assert (help4.sum(axis=1) > 0).any(), "no column was split: the helper-list path is not exercised"
+    o = oracle_like(g, I)
+    vec, num = np.zeros(I["n"]), 0
+    for w in range(3):
+        assert g.solve_iter_l2f(100 * w, 100 * (w + 1), vec, num) == o.solve_iter_l2f(100 * w, 100 * (w + 1), vec, num)
+        xg = g.get_x_iters_2d(100)
+        assert bits_equal(xg, o.get_x_iters_2d(100)), w
+        vec, num = scripted_fix_vec(xg, lo=0.05, hi=0.95, last=10)
+        if num <= 10:
+            num = 0
+    assert g.cal_Obj() == o.cal_Obj() and g.get_n() == o.get_n()
