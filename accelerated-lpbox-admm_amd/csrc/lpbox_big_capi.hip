@@ -401,10 +401,14 @@ static int run_window(lpbox_big *h, const BigDev &d, int iter_end) {
         int batch = std::min(std::max(remaining, 0), 16);
         if (h->use_graph && !h->ag && batch >= BIG_ITERS_PER_GRAPH) {
             hipGraphExec_t ex = nullptr;
-            CHK(ensure_graph(h, d, &ex));
-            for (; batch >= BIG_ITERS_PER_GRAPH; batch -= BIG_ITERS_PER_GRAPH) {
-                HIPCHK(hipGraphLaunch(ex, h->stream));
-                h->launches += h->graph_launches; h->collectives += h->graph_collectives;
+            if (ensure_graph(h, d, &ex) < 0) {          // a transport that cannot be captured: go on with eager launches for good
+                h->use_graph = false;
+                (void)hipGetLastError();
+            } else {
+                for (; batch >= BIG_ITERS_PER_GRAPH; batch -= BIG_ITERS_PER_GRAPH) {
+                    HIPCHK(hipGraphLaunch(ex, h->stream));
+                    h->launches += h->graph_launches; h->collectives += h->graph_collectives;
+                }
             }
         }
         for (int it = 0; it < batch; it++) CHK(enqueue_iteration(h, d));
