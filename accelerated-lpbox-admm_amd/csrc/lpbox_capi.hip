@@ -835,6 +835,22 @@ int lpbox_policy_encode_f16(const double *x_dev, const long long *row_off_dev, l
     return LPBOX_OK;
 }
 
+int lpbox_policy_f32_layout(int tokens, long *weight_floats) {
+    if (tokens != 20 && tokens != 5) return fail(LPBOX_E_BADARG, "tokens must be 20 (LP) or 5 (segmentation)");
+    if (weight_floats) *weight_floats = policy_f32_weight_floats(tokens);
+    return LPBOX_OK;
+}
+
+int lpbox_policy_score_f32(const double *x_dev, const long long *row_off_dev, long rows, int tokens, int tok_stride,
+                           const float *weights_dev, float *sigmoid_dev, float *logit_dev, void *hip_stream) {
+    if (tokens != 20 && tokens != 5) return fail(LPBOX_E_BADARG, "tokens must be 20 (LP) or 5 (segmentation)");
+    if (rows < 0 || tok_stride < 1) return fail(LPBOX_E_BADARG, "bad rows / token stride");
+    if (rows == 0) return LPBOX_OK;
+    if (!x_dev || !row_off_dev || !weights_dev || !sigmoid_dev) return fail(LPBOX_E_BADARG, "null device pointer");
+    HIPCHK(policy_launch_f32(x_dev, row_off_dev, rows, tokens, tok_stride, weights_dev, sigmoid_dev, logit_dev, (hipStream_t)hip_stream));
+    return LPBOX_OK;
+}
+
 int lpbox_set_active(lpbox_t *h, const int *active) {
     if (!valid_handle(h) || h->seg) return fail(LPBOX_E_BADHANDLE, "bad handle (LP flavour only)");
     if (!h->inited) return fail(LPBOX_E_STATE, "solve_init has not been called");

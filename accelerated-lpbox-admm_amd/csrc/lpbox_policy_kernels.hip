@@ -378,3 +378,184 @@ hipError_t policy_launch_body(const PolicyArgs &pa, int tokens, hipStream_t s) {
     }
     return hipGetLastError();
 }
+
+// =====================================================================================================================
+// The WHOLE network in fp32 (the reference's arithmetic: LP/mha.py:202-249 evaluates in float32), one workgroup per variable.
+// Not a fast path: plain FMA loops, weights streamed from L2, activations in LDS.  It exists so that a fixing decision near a
+// threshold is taken by fp32 arithmetic on the device without leaving this library (lpbox_hip.policy.FusedEarlyFixPolicy re-scores
+// the rows whose fp16 score lies within its decision band of 0.9 / 0.1 with it), and as the fp32 reference of the fused kernel.
+// Weight layout (floats, lpbox_hip/policy.py packs it): W_in (5x128) | position bias (TOK x 128) | per layer: W_qkv (128x384,
+// columns Q|K|V, head h = columns 16h..16h+15 of each third) W_o (128x128) s1 t1 (128 each) W_1 (128x512) b1 (512) W_2 (512x128)
+// b2 s2 t2 (128 each) | head: fc1 (TOK*128 x 256) b (256) fc2 (256x128) b (128) fc3 (128x16) b (16) fc4 (16) b (1).
+// =====================================================================================================================
+namespace {
+
+constexpr int F32_T = 256;
+constexpr long f32_layer_floats() { return 128L * 384 + 128 * 128 + 128 + 128 + 128 * 512 + 512 + 512 * 128 + 128 + 128 + 128; }
+
+template <int TOK>
+__global__ void __launch_bounds__(F32_T) policy_f32_kernel(const double *x, const long long *row_off, long rows, int tok_stride,
+                                                           const float *W, float *out_sig, float *out_logit) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *h = reinterpret_cast<float *>(smem);          // [TOK][128]
+    float *qkv = h + TOK * 128;                          // [TOK][384]; later the head's intermediate vectors
+    float *ao = qkv + TOK * 384;                         // [TOK][128]
+    float *ff = ao + TOK * 128;                          // [TOK][512]
+    float *xs = ff + TOK * 512;                          // [TOK][5]
+    const int t = threadIdx.x;
+    const long var = blockIdx.x;
+    if (var >= rows) return;
+    const float *w_in = W, *b_in = W + 5 * 128, *layer0 = b_in + TOK * 128;
+    const float *head = layer0 + 2 * f32_layer_floats();
+    if (t < TOK * 5) xs[t] = (float)x[row_off[var] + (long)(t / 5) * tok_stride + t % 5];
+    __syncthreads();
+    for (int e = t; e < TOK * 128; e += F32_T) {
+        const int tok = e >> 7, f = e & 127;
+        float a = b_in[tok * 128 + f];
+#pragma unroll
+        for (int c = 0; c < 5; c++) a += xs[tok * 5 + c] * w_in[c * 128 + f];
+        h[e] = a;
+    }
+    __syncthreads();
+    const int col = t & 127, tok0 = t >> 7;              // 128-column stages: two threads per column, tokens tok0, tok0 + 2, ...
+    constexpr int TH = (TOK + 1) / 2;
+    for (int layer = 0; layer < 2; layer++) {
+        const float *wqkv = layer0 + layer * f32_layer_floats(), *wo = wqkv + 128 * 384, *s1 = wo + 128 * 128, *t1 = s1 + 128;
+        const float *w1 = t1 + 128, *b1 = w1 + 128 * 512, *w2 = b1 + 512, *b2 = w2 + 512 * 128, *s2 = b2 + 128, *t2 = s2 + 128;
+        for (int j = t; j < 384; j += F32_T) {           // Q | K | V
+            float acc[TOK];
+#pragma unroll
+            for (int k = 0; k < TOK; k++) acc[k] = 0.f;
+            for (int k = 0; k < 128; k += 4) {          // four weights per 16-byte LDS read of the activations (the LDS issue rate binds)
+                const float w0 = wqkv[k * 384 + j], w1_ = wqkv[(k + 1) * 384 + j], w2_ = wqkv[(k + 2) * 384 + j], w3 = wqkv[(k + 3) * 384 + j];
+#pragma unroll
+                for (int tk = 0; tk < TOK; tk++) {
+                    const f32x4 hv = *(const f32x4 *)(h + tk * 128 + k);
+                    acc[tk] += hv[0] * w0 + hv[1] * w1_ + hv[2] * w2_ + hv[3] * w3;
+                }
+            }
+#pragma unroll
+            for (int tk = 0; tk < TOK; tk++) qkv[tk * 384 + j] = acc[tk];
+        }
+        __syncthreads();
+        for (int pr = t; pr < 8 * TOK; pr += F32_T) {    // one (head, query) pair per thread: softmax(q.k / sqrt(16)) v  (mha.py:42, :86-104)
+            const int hh = pr / TOK, qi = pr - hh * TOK;
+            float s[TOK], mx = -3.0e38f;
+#pragma unroll
+            for (int j = 0; j < TOK; j++) {
+                float d = 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; e++) d += qkv[qi * 384 + hh * 16 + e] * qkv[j * 384 + 128 + hh * 16 + e];
+                s[j] = d * 0.25f;
+                mx = fmaxf(mx, s[j]);
+            }
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < TOK; j++) { s[j] = expf(s[j] - mx); sum += s[j]; }
+            const float inv = 1.f / sum;
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                float o = 0.f;
+#pragma unroll
+                for (int j = 0; j < TOK; j++) o += (s[j] * inv) * qkv[j * 384 + 256 + hh * 16 + e];
+                ao[qi * 128 + hh * 16 + e] = o;
+            }
+        }
+        __syncthreads();
+        {                                                // output projection + residual + BatchNorm (eval)
+            float acc[TH];
+#pragma unroll
+            for (int k = 0; k < TH; k++) acc[k] = 0.f;
+            for (int k = 0; k < 128; k += 4) {
+                const float w0 = wo[k * 128 + col], w1_ = wo[(k + 1) * 128 + col], w2_ = wo[(k + 2) * 128 + col], w3 = wo[(k + 3) * 128 + col];
+#pragma unroll
+                for (int i = 0; i < TH; i++) {
+                    const int tk = tok0 + 2 * i;
+                    if (tk < TOK) { const f32x4 v = *(const f32x4 *)(ao + tk * 128 + k); acc[i] += v[0] * w0 + v[1] * w1_ + v[2] * w2_ + v[3] * w3; }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TH; i++) { const int tk = tok0 + 2 * i; if (tk < TOK) h[tk * 128 + col] = (h[tk * 128 + col] + acc[i]) * s1[col] + t1[col]; }
+        }
+        __syncthreads();
+        for (int j = t; j < 512; j += F32_T) {           // FF up + ReLU
+            float acc[TOK];
+#pragma unroll
+            for (int k = 0; k < TOK; k++) acc[k] = 0.f;
+            for (int k = 0; k < 128; k += 4) {
+                const float w0 = w1[k * 512 + j], w1_ = w1[(k + 1) * 512 + j], w2_ = w1[(k + 2) * 512 + j], w3 = w1[(k + 3) * 512 + j];
+#pragma unroll
+                for (int tk = 0; tk < TOK; tk++) {
+                    const f32x4 hv = *(const f32x4 *)(h + tk * 128 + k);
+                    acc[tk] += hv[0] * w0 + hv[1] * w1_ + hv[2] * w2_ + hv[3] * w3;
+                }
+            }
+#pragma unroll
+            for (int tk = 0; tk < TOK; tk++) ff[tk * 512 + j] = fmaxf(acc[tk] + b1[j], 0.f);
+        }
+        __syncthreads();
+        {                                                // FF down + residual + BatchNorm (eval)
+            float acc[TH];
+#pragma unroll
+            for (int k = 0; k < TH; k++) acc[k] = 0.f;
+            for (int k = 0; k < 512; k += 4) {
+                const float w0 = w2[k * 128 + col], w1_ = w2[(k + 1) * 128 + col], w2_ = w2[(k + 2) * 128 + col], w3 = w2[(k + 3) * 128 + col];
+#pragma unroll
+                for (int i = 0; i < TH; i++) {
+                    const int tk = tok0 + 2 * i;
+                    if (tk < TOK) { const f32x4 v = *(const f32x4 *)(ff + tk * 512 + k); acc[i] += v[0] * w0 + v[1] * w1_ + v[2] * w2_ + v[3] * w3; }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TH; i++) { const int tk = tok0 + 2 * i; if (tk < TOK) h[tk * 128 + col] = (h[tk * 128 + col] + acc[i] + b2[col]) * s2[col] + t2[col]; }
+        }
+        __syncthreads();
+    }
+    // head: flatten (TOK*128) -> 256 -> 128 -> 16 -> 1, ReLU between (mha.py:185-199, :240-247)
+    const float *f1 = head, *c1 = f1 + (long)TOK * 128 * 256, *f2 = c1 + 256, *c2 = f2 + 256 * 128, *f3 = c2 + 128, *c3 = f3 + 128 * 16,
+                *f4 = c3 + 16, *c4 = f4 + 16;
+    float *z1 = qkv, *z2 = qkv + 256, *z3 = qkv + 384;
+    {
+        float a = c1[t];
+        for (int i = 0; i < TOK * 128; i += 4) {
+            const f32x4 hv = *(const f32x4 *)(h + i);
+            a += hv[0] * f1[(long)i * 256 + t] + hv[1] * f1[(long)(i + 1) * 256 + t] + hv[2] * f1[(long)(i + 2) * 256 + t] + hv[3] * f1[(long)(i + 3) * 256 + t];
+        }
+        z1[t] = fmaxf(a, 0.f);
+    }
+    __syncthreads();
+    if (t < 128) { float a = c2[t]; for (int i = 0; i < 256; i++) a += z1[i] * f2[i * 128 + t]; z2[t] = fmaxf(a, 0.f); }
+    __syncthreads();
+    if (t < 16) { float a = c3[t]; for (int i = 0; i < 128; i++) a += z2[i] * f3[i * 16 + t]; z3[t] = fmaxf(a, 0.f); }
+    __syncthreads();
+    if (t == 0) {
+        float a = c4[0];
+        for (int i = 0; i < 16; i++) a += z3[i] * f4[i];
+        if (out_logit) out_logit[var] = a;
+        out_sig[var] = 1.f / (1.f + expf(-a));
+    }
+}
+
+}  // namespace
+
+long policy_f32_weight_floats(int tokens) {
+    return 5L * 128 + (long)tokens * 128 + 2 * f32_layer_floats() + (long)tokens * 128 * 256 + 256 + 256 * 128 + 128 + 128 * 16 + 16 + 16 + 1;
+}
+
+hipError_t policy_launch_f32(const double *x, const long long *row_off, long rows, int tokens, int tok_stride, const float *W,
+                             float *out_sig, float *out_logit, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    const size_t lds = sizeof(float) * (size_t)tokens * (128 + 384 + 128 + 512 + 5);
+    if (tokens == 20) {
+        hipError_t e = hipFuncSetAttribute((const void *)policy_f32_kernel<20>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(policy_f32_kernel<20>, dim3((unsigned)rows), dim3(F32_T), lds, s, x, row_off, rows, tok_stride, W, out_sig, out_logit);
+    } else if (tokens == 5) {
+        hipError_t e = hipFuncSetAttribute((const void *)policy_f32_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(policy_f32_kernel<5>, dim3((unsigned)rows), dim3(F32_T), lds, s, x, row_off, rows, tok_stride, W, out_sig, out_logit);
+    } else {
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}

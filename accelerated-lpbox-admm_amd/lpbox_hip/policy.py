@@ -159,6 +159,57 @@ def _pack_fragments(w):
     return v.reshape(NT * KS * 64 * 8).to(torch.float16)
 
 
+class HipFp32Policy:
+    """The whole network (encoder + MLP head) in fp32 by ONE plain HIP kernel, one workgroup per variable (C-ABI
+    lpbox_policy_score_f32): the reference's float32 arithmetic on the device without torch in the path.  Slow by design (FMA
+    loops, ~20x the fused fp16 encoder); FusedEarlyFixPolicy uses it for the rows whose score lies near a fixing threshold, and the
+    tests use it as the fp32 check of the fused kernel.  Agreement with the reference module: rounding (tested at 1e-4 on the
+    sigmoid against the reference-generated golden vectors, 2e-5 against EarlyFixPolicy)."""
+
+    def __init__(self, state_dict, tokens=20, device="cuda"):
+        import ctypes as C
+        from . import _lib
+        self._L, self._check, self._C = _lib.load(), _lib.check, C
+        ref = EarlyFixPolicy(state_dict, tokens=tokens, device="cpu")          # validates names/shapes, folds BN and the position code
+        self.tokens, self.device = tokens, torch.device(device)
+        parts = [ref.w_in, ref.b_in]
+        for L in ref.layers:
+            parts += [L["w_qkv"], L["w_o"], L["n1_s"], L["n1_t"], L["w1"], L["b1"], L["w2"], L["b2"], L["n2_s"], L["n2_t"]]
+        for w, b in ref.head:
+            parts += [w, b]
+        flat = torch.cat([t.reshape(-1).to(torch.float32) for t in parts])
+        n = C.c_long()
+        self._check(self._L.lpbox_policy_f32_layout(tokens, C.byref(n)), "lpbox_policy_f32_layout")
+        assert flat.numel() == n.value, (flat.numel(), n.value)
+        self.w = flat.contiguous().to(self.device)
+
+    @classmethod
+    def random(cls, tokens=20, seed=0, **kw):
+        return cls(random_state(tokens, seed), tokens=tokens, **kw)
+
+    @torch.no_grad()
+    def scores_from_xiters(self, flat, row_off, tok_stride=None, logits=False):
+        rows = int(row_off.numel())
+        sig = torch.empty(rows, device=self.device, dtype=torch.float32)
+        lg = torch.empty(rows, device=self.device, dtype=torch.float32) if logits else None
+        if rows:
+            ts = CODE_DIM if tok_stride is None else int(tok_stride)
+            if int(row_off.max().item()) + (self.tokens - 1) * ts + CODE_DIM > flat.numel():
+                raise ValueError("row offsets reach past the end of the iterate buffer")
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            row_off = row_off.contiguous()
+            self._check(self._L.lpbox_policy_score_f32(flat.data_ptr(), row_off.data_ptr(), rows, self.tokens, ts, self.w.data_ptr(),
+                                                       sig.data_ptr(), lg.data_ptr() if logits else None, stream), "lpbox_policy_score_f32")
+        return (sig, lg) if logits else sig
+
+    def __call__(self, x):
+        x = x.to(self.device, torch.float64).contiguous()
+        if x.dim() != 3 or x.shape[1] != self.tokens or x.shape[2] != CODE_DIM:
+            raise ValueError("expected (rows, %d, %d), got %s" % (self.tokens, CODE_DIM, tuple(x.shape)))
+        off = torch.arange(x.shape[0], device=self.device, dtype=torch.int64) * (self.tokens * CODE_DIM)
+        return self.scores_from_xiters(x.reshape(-1), off, CODE_DIM)
+
+
 class FusedEarlyFixPolicy:
     """Same scores as EarlyFixPolicy, computed by the fused fp16-MFMA encoder kernel + a half-precision head.
 
@@ -167,8 +218,8 @@ class FusedEarlyFixPolicy:
     fp32 network on the sigmoid for weights drawn like the reference initialises them, within 2e-2 on the formula-weight stress
     fixture (both tested, tests/test_policy.py).  The callers threshold the score at 0.9 / 0.1 (deter_fix_2, LP/trainer.py:101-135),
     so a score within that error of a threshold could fix a different variable set than the reference's fp32 arithmetic: every
-    row whose fp16 score lies within `decision_band` of 0.9 or 0.1 is therefore RE-SCORED by the fp32 evaluation (EarlyFixPolicy
-    on the same device, a few rows per window), which makes the fix decisions those of the fp32 network (tested).
+    row whose fp16 score lies within `decision_band` of 0.9 or 0.1 is therefore RE-SCORED in fp32 by the plain HIP kernel of the same
+    library (HipFp32Policy, a few rows per window), which makes the fix decisions those of the fp32 network (tested).
     decision_band = 0 turns the re-scoring off (pure fp16 fast mode)."""
 
     def __init__(self, state_dict, tokens=20, device="cuda", chunk_rows=262144, decision_band=3e-2, thresholds=(0.9, 0.1)):
@@ -200,7 +251,7 @@ class FusedEarlyFixPolicy:
         self.c = c.contiguous().to(self.device)
         self.head = [(wt.to(self.device, torch.float16), b.to(self.device, torch.float16)) for wt, b in ref.head]
         self.decision_band, self.thresholds = float(decision_band), tuple(thresholds)
-        self.ref32 = EarlyFixPolicy(state_dict, tokens=tokens, device=device) if self.decision_band > 0 else None
+        self.ref32 = HipFp32Policy(state_dict, tokens=tokens, device=device) if self.decision_band > 0 else None   # fp32 HIP kernel, same library
         self.rescored = 0                      # rows re-scored in fp32 so far (diagnostic)
 
     @classmethod
@@ -243,10 +294,7 @@ class FusedEarlyFixPolicy:
                 near |= (sig - t).abs() < self.decision_band
             idx = near.nonzero().flatten()
             if idx.numel():                     # decisions near a threshold: the reference's fp32 arithmetic decides
-                ts = CODE_DIM if tok_stride is None else int(tok_stride)
-                g = (row_off[idx].view(-1, 1, 1) + (torch.arange(self.tokens, device=self.device) * ts).view(1, -1, 1)
-                     + torch.arange(CODE_DIM, device=self.device).view(1, 1, -1))
-                sig[idx] = self.ref32(flat[g].to(torch.float32)).to(sig.dtype)
+                sig[idx] = self.ref32.scores_from_xiters(flat, row_off[idx], tok_stride).to(sig.dtype)
                 self.rescored += int(idx.numel())
         return sig
 

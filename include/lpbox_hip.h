@@ -101,6 +101,13 @@ int lpbox_seg_get_x_history(lpbox_t *h, int first, int count, double *out);
 int lpbox_policy_layout(int tokens, long *weight_halves, long *const_floats);
 int lpbox_policy_encode_f16(const double *x_dev, const long long *row_off_dev, long rows, int tokens, int tok_stride,
                             const void *weights_dev, const float *consts_dev, void *out_dev, void *hip_stream);
+/* The whole network -- encoder and MLP head -- in fp32 on the device, one workgroup per variable: the reference's arithmetic
+ * (LP/mha.py evaluates in float32), for fixing decisions near a threshold and as the fp32 check of the fused kernel; not a fast
+ * path.  weights_dev: floats in the order csrc/lpbox_policy_kernels.hip documents (lpbox_policy_f32_layout gives the count);
+ * sigmoid_dev[rows] (and logit_dev[rows] if not NULL) receive the scores.  Asynchronous on hip_stream. */
+int lpbox_policy_f32_layout(int tokens, long *weight_floats);
+int lpbox_policy_score_f32(const double *x_dev, const long long *row_off_dev, long rows, int tokens, int tok_stride,
+                           const float *weights_dev, float *sigmoid_dev, float *logit_dev, void *hip_stream);
 /* Batched use only: park (active[i] == 0) or resume instances.  A parked instance is skipped by lpbox_iterate / _l2f and keeps its
  * state and return code; the reference has no counterpart because its loop simply stops calling a finished solver
  * (LP/trainer.py:511-512).  active == NULL resumes all. */

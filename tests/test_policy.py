@@ -86,6 +86,28 @@ def test_fused_encoder_matches_reference_gpu(tag, tokens):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("tag,tokens", [("lp", 20), ("seg", 5)])
+def test_fp32_hip_kernel_matches_reference(tag, tokens):
+    """lpbox_policy_score_f32 (the whole network in fp32 by one plain HIP kernel): 1e-4 on the sigmoid against the golden vectors the
+    reference module produced, 2e-5 against the fp32 torch evaluation, also through an x_iters-style fp64 buffer with strided tokens."""
+    sd = deterministic_state(P.reference_state_shapes(tokens))
+    hip32, ref = P.HipFp32Policy(sd, tokens=tokens, device="cuda"), P.EarlyFixPolicy(sd, tokens=tokens, device="cuda")
+    x = torch.from_numpy(FIX[tag + "_x"]).cuda()
+    got = hip32(x).cpu().numpy()
+    assert np.abs(got - FIX[tag + "_sigmoid"]).max() < 1e-4
+    assert np.abs(got - ref(x).cpu().numpy()).max() < 2e-5
+    sig, logit = hip32.scores_from_xiters(x.to(torch.float64).reshape(-1), torch.arange(x.shape[0], device="cuda") * (tokens * 5), 5, logits=True)
+    assert np.abs(logit.cpu().numpy() - FIX[tag + "_logit"]).max() < 5e-4 * max(1.0, np.abs(FIX[tag + "_logit"]).max())
+    # SEG-style overlapping tokens: token j = iterates j .. j+4 of a 10-iterate window (stride 1)
+    if tokens == 5:
+        g = torch.Generator().manual_seed(11)
+        w = torch.rand(300, 10, generator=g, dtype=torch.float64).cuda()
+        xs = torch.stack([w[:, j:j + 5] for j in range(5)], dim=1).to(torch.float32)
+        a = hip32.scores_from_xiters(w.reshape(-1), torch.arange(300, device="cuda") * 10, 1)
+        assert (a - ref(xs)).abs().max().item() < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,tokens", [("lp", 20), ("seg", 5)])
 def test_fused_policy_takes_the_fp32_fix_decisions(tag, tokens):
     """deter_fix_2 thresholds the score at 0.9 / 0.1: with the default decision band the fused path re-scores the rows near a
     threshold in fp32, so its FIX VECTOR equals the one the fp32 network (= the reference's arithmetic, pinned by the golden
