@@ -847,7 +847,18 @@ int lpbox_policy_score_f32(const double *x_dev, const long long *row_off_dev, lo
     if (rows < 0 || tok_stride < 1) return fail(LPBOX_E_BADARG, "bad rows / token stride");
     if (rows == 0) return LPBOX_OK;
     if (!x_dev || !row_off_dev || !weights_dev || !sigmoid_dev) return fail(LPBOX_E_BADARG, "null device pointer");
-    HIPCHK(policy_launch_f32(x_dev, row_off_dev, rows, tokens, tok_stride, weights_dev, sigmoid_dev, logit_dev, (hipStream_t)hip_stream));
+    HIPCHK(policy_launch_f32(x_dev, row_off_dev, rows, tokens, tok_stride, weights_dev, sigmoid_dev, logit_dev, 0.f, 0.f, 0.f, nullptr, (hipStream_t)hip_stream));
+    return LPBOX_OK;
+}
+
+int lpbox_policy_rescore_f32(const double *x_dev, const long long *row_off_dev, long rows, int tokens, int tok_stride,
+                             const float *weights_dev, float *sigmoid_dev, float band, float thr_hi, float thr_lo,
+                             unsigned long long *count_dev, void *hip_stream) {
+    if (tokens != 20 && tokens != 5) return fail(LPBOX_E_BADARG, "tokens must be 20 (LP) or 5 (segmentation)");
+    if (rows < 0 || tok_stride < 1 || !(band > 0.f)) return fail(LPBOX_E_BADARG, "bad rows / token stride / band");
+    if (rows == 0) return LPBOX_OK;
+    if (!x_dev || !row_off_dev || !weights_dev || !sigmoid_dev) return fail(LPBOX_E_BADARG, "null device pointer");
+    HIPCHK(policy_launch_f32(x_dev, row_off_dev, rows, tokens, tok_stride, weights_dev, sigmoid_dev, nullptr, band, thr_hi, thr_lo, count_dev, (hipStream_t)hip_stream));
     return LPBOX_OK;
 }
 

@@ -38,4 +38,5 @@ hipError_t policy_launch_body(const PolicyArgs &pa, int tokens, hipStream_t s);
 // the whole network in fp32, one workgroup per variable (reference arithmetic; used for decisions near a threshold)
 long policy_f32_weight_floats(int tokens);
 hipError_t policy_launch_f32(const double *x, const long long *row_off, long rows, int tokens, int tok_stride, const float *W,
-                             float *out_sig, float *out_logit, hipStream_t s);
+                             float *out_sig, float *out_logit, float band, float thr_hi, float thr_lo, unsigned long long *rescored,
+                             hipStream_t s);

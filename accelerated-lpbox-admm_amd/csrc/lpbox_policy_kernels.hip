@@ -23,6 +23,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "lpbox_policy.h"
 
 // timing experiments only (tools/): -DPOL_NO_ATTN / -DPOL_NO_FF cut a phase out; results are then wrong by construction
@@ -393,9 +395,12 @@ namespace {
 constexpr int F32_T = 256;
 constexpr long f32_layer_floats() { return 128L * 384 + 128 * 128 + 128 + 128 + 128 * 512 + 512 + 512 * 128 + 128 + 128 + 128; }
 
+// band > 0: out_sig holds scores already (the fused fp16 path's); only the variables whose score lies within `band` of thr_hi or thr_lo
+// are evaluated and overwritten, and *rescored counts them -- no host round trip to find them.
 template <int TOK>
 __global__ void __launch_bounds__(F32_T) policy_f32_kernel(const double *x, const long long *row_off, long rows, int tok_stride,
-                                                           const float *W, float *out_sig, float *out_logit) {
+                                                           const float *W, float *out_sig, float *out_logit, float band, float thr_hi,
+                                                           float thr_lo, unsigned long long *rescored) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *h = reinterpret_cast<float *>(smem);          // [TOK][128]
     float *qkv = h + TOK * 128;                          // [TOK][384]; later the head's intermediate vectors
@@ -403,10 +408,15 @@ __global__ void __launch_bounds__(F32_T) policy_f32_kernel(const double *x, cons
     float *ff = ao + TOK * 128;                          // [TOK][512]
     float *xs = ff + TOK * 512;                          // [TOK][5]
     const int t = threadIdx.x;
-    const long var = blockIdx.x;
-    if (var >= rows) return;
     const float *w_in = W, *b_in = W + 5 * 128, *layer0 = b_in + TOK * 128;
     const float *head = layer0 + 2 * f32_layer_floats();
+    for (long var = blockIdx.x; var < rows; var += gridDim.x) {
+    if (band > 0.f) {                                    // uniform over the workgroup
+        const float sc = out_sig[var];
+        if (!(fabsf(sc - thr_hi) < band || fabsf(sc - thr_lo) < band)) continue;
+        if (t == 0 && rescored) atomicAdd(rescored, 1ull);
+    }
+    __syncthreads();                                     // the previous variable's head has finished with the LDS buffers
     if (t < TOK * 5) xs[t] = (float)x[row_off[var] + (long)(t / 5) * tok_stride + t % 5];
     __syncthreads();
     for (int e = t; e < TOK * 128; e += F32_T) {
@@ -534,6 +544,7 @@ __global__ void __launch_bounds__(F32_T) policy_f32_kernel(const double *x, cons
         if (out_logit) out_logit[var] = a;
         out_sig[var] = 1.f / (1.f + expf(-a));
     }
+    }
 }
 
 }  // namespace
@@ -543,17 +554,19 @@ long policy_f32_weight_floats(int tokens) {
 }
 
 hipError_t policy_launch_f32(const double *x, const long long *row_off, long rows, int tokens, int tok_stride, const float *W,
-                             float *out_sig, float *out_logit, hipStream_t s) {
+                             float *out_sig, float *out_logit, float band, float thr_hi, float thr_lo, unsigned long long *rescored,
+                             hipStream_t s) {
     if (rows <= 0) return hipSuccess;
+    const unsigned grid = (unsigned)std::min<long>(rows, band > 0.f ? 2048 : 65535L * 16);
     const size_t lds = sizeof(float) * (size_t)tokens * (128 + 384 + 128 + 512 + 5);
     if (tokens == 20) {
         hipError_t e = hipFuncSetAttribute((const void *)policy_f32_kernel<20>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(policy_f32_kernel<20>, dim3((unsigned)rows), dim3(F32_T), lds, s, x, row_off, rows, tok_stride, W, out_sig, out_logit);
+        hipLaunchKernelGGL(policy_f32_kernel<20>, dim3(grid), dim3(F32_T), lds, s, x, row_off, rows, tok_stride, W, out_sig, out_logit, band, thr_hi, thr_lo, rescored);
     } else if (tokens == 5) {
         hipError_t e = hipFuncSetAttribute((const void *)policy_f32_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(policy_f32_kernel<5>, dim3((unsigned)rows), dim3(F32_T), lds, s, x, row_off, rows, tok_stride, W, out_sig, out_logit);
+        hipLaunchKernelGGL(policy_f32_kernel<5>, dim3(grid), dim3(F32_T), lds, s, x, row_off, rows, tok_stride, W, out_sig, out_logit, band, thr_hi, thr_lo, rescored);
     } else {
         return hipErrorInvalidValue;
     }

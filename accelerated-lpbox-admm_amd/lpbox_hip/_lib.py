@@ -44,6 +44,7 @@ SYMBOLS = {
     "lpbox_policy_encode_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lpbox_policy_f32_layout": (C.c_int, [C.c_int, C.POINTER(C.c_long)]),
     "lpbox_policy_score_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lpbox_policy_rescore_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "lpbox_set_active": (C.c_int, [C.c_void_p, C.c_void_p]),
     "lpbox_get_x_iters_device": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_long)]),
     "lpbox_get_x_sol": (C.c_int, [C.c_void_p, C.c_int, _dp]),

@@ -202,6 +202,19 @@ class HipFp32Policy:
                                                        sig.data_ptr(), lg.data_ptr() if logits else None, stream), "lpbox_policy_score_f32")
         return (sig, lg) if logits else sig
 
+    @torch.no_grad()
+    def rescore_band(self, flat, row_off, sig, band, thresholds, tok_stride=None, counter=None):
+        """In place: the entries of `sig` (float32 CUDA) within `band` of a threshold are replaced by the fp32 evaluation; the
+        selection runs on the device (no host synchronisation).  `counter`: optional int64 CUDA tensor (1,) incremented per re-scored row."""
+        rows = int(row_off.numel())
+        if rows:
+            ts = CODE_DIM if tok_stride is None else int(tok_stride)
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            self._check(self._L.lpbox_policy_rescore_f32(flat.data_ptr(), row_off.contiguous().data_ptr(), rows, self.tokens, ts, self.w.data_ptr(),
+                                                         sig.data_ptr(), float(band), float(thresholds[0]), float(thresholds[1]),
+                                                         counter.data_ptr() if counter is not None else None, stream), "lpbox_policy_rescore_f32")
+        return sig
+
     def __call__(self, x):
         x = x.to(self.device, torch.float64).contiguous()
         if x.dim() != 3 or x.shape[1] != self.tokens or x.shape[2] != CODE_DIM:
@@ -252,7 +265,7 @@ class FusedEarlyFixPolicy:
         self.head = [(wt.to(self.device, torch.float16), b.to(self.device, torch.float16)) for wt, b in ref.head]
         self.decision_band, self.thresholds = float(decision_band), tuple(thresholds)
         self.ref32 = HipFp32Policy(state_dict, tokens=tokens, device=device) if self.decision_band > 0 else None   # fp32 HIP kernel, same library
-        self.rescored = 0                      # rows re-scored in fp32 so far (diagnostic)
+        self._rescored = torch.zeros(1, dtype=torch.int64, device=self.device)
 
     @classmethod
     def random(cls, tokens=20, seed=0, **kw):
@@ -288,15 +301,14 @@ class FusedEarlyFixPolicy:
     @torch.no_grad()
     def scores_from_xiters(self, flat, row_off, tok_stride=None):
         sig = torch.sigmoid(self.logits_from_xiters(flat, row_off, tok_stride))
-        if self.ref32 is not None and sig.numel():
-            near = torch.zeros_like(sig, dtype=torch.bool)
-            for t in self.thresholds:
-                near |= (sig - t).abs() < self.decision_band
-            idx = near.nonzero().flatten()
-            if idx.numel():                     # decisions near a threshold: the reference's fp32 arithmetic decides
-                sig[idx] = self.ref32.scores_from_xiters(flat, row_off[idx], tok_stride).to(sig.dtype)
-                self.rescored += int(idx.numel())
+        if self.ref32 is not None and sig.numel():      # decisions near a threshold: the reference's fp32 arithmetic decides (selected on the device)
+            self.ref32.rescore_band(flat, row_off, sig, self.decision_band, self.thresholds, tok_stride, self._rescored)
         return sig
+
+    @property
+    def rescored(self):
+        """Rows re-scored in fp32 so far (diagnostic; reading it synchronises)."""
+        return int(self._rescored.item()) if self.ref32 is not None else 0
 
     def logits(self, x):
         x = x.to(self.device, torch.float64).contiguous()

@@ -108,6 +108,12 @@ int lpbox_policy_encode_f16(const double *x_dev, const long long *row_off_dev, l
 int lpbox_policy_f32_layout(int tokens, long *weight_floats);
 int lpbox_policy_score_f32(const double *x_dev, const long long *row_off_dev, long rows, int tokens, int tok_stride,
                            const float *weights_dev, float *sigmoid_dev, float *logit_dev, void *hip_stream);
+/* The same kernel as a filter: sigmoid_dev[rows] already holds scores (the fused fp16 path's); every variable whose score lies within
+ * `band` of thr_hi or thr_lo is re-evaluated in fp32 and overwritten, the others are left alone; *count_dev (optional, device) is
+ * incremented per re-scored variable.  No host round trip: the selection happens on the device. */
+int lpbox_policy_rescore_f32(const double *x_dev, const long long *row_off_dev, long rows, int tokens, int tok_stride,
+                             const float *weights_dev, float *sigmoid_dev, float band, float thr_hi, float thr_lo,
+                             unsigned long long *count_dev, void *hip_stream);
 /* Batched use only: park (active[i] == 0) or resume instances.  A parked instance is skipped by lpbox_iterate / _l2f and keeps its
  * state and return code; the reference has no counterpart because its loop simply stops calling a finished solver
  * (LP/trainer.py:511-512).  active == NULL resumes all. */

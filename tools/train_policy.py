@@ -40,3 +40,5 @@ for name, pol in (("fp32 torch", EarlyFixPolicy(net.state_dict(), tokens=20, dev
     print("%s: %.1f ms (solve %.1f policy %.1f host %.1f), windows %d, mean iterations %.0f, fixed %.1f%% of variables, objective gap mean %+.4f (min %+.4f max %+.4f), infeasible %d" % (
         name, dt * 1e3, tm["solve"] * 1e3, tm["policy"] * 1e3, tm["host"] * 1e3, res["windows"], its.mean(), 100.0 * fixed / sum(I["n"] for I in test_set),
         gap.mean(), gap.min(), gap.max(), int((res["infeasible"] > 0).sum())))
+    if hasattr(pol, "rescored"):
+        print("   rows re-scored in fp32 (decision band) over both repetitions: %d" % pol.rescored)
