@@ -6,6 +6,8 @@ oracle parity to convergence for three of them.
 Config 5 (world = 1): the n = 10^6 instance -- determinism, objective and feasibility recomputed on the host, and bit-exact
 iterates against the oracle at the largest size the oracle manages in under a minute.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -96,3 +98,35 @@ def test_config5_windows_bit_exact_at_full_size(n, seed):
             assert bits_equal(g.vec(name), o.vec(name)), (s, e, name)
         assert (g.scalar("outer_total"), g.scalar("pcg_total")) == (o.total_outer_iters, o.total_pcg_iters)
         assert g.scalar("cur_obj") == o.scalar("cur_obj")
+
+
+def _oracle_full_solve(args):
+    """Worker (CPU): one instance solved to convergence by the oracle in the kernels' association."""
+    I, T, npos, pos, rs, cs = args
+    from oracle import oracle as O
+    s = O.LpOracle(0, order=O.ORDER_GPU, T=T, positions=pos, npos=npos, row_split=rs, col_split=cs)
+    s.set_problem(I["n"], I["l"], I["colptr"], I["rowidx"], I["b"])
+    s.solve_init()
+    ret = s.solve_iter(0, 20000)
+    return ret, s.total_outer_iters, s.total_pcg_iters, s.cal_Obj(), s.vec("x"), s.get_x_sol().ravel()
+
+
+@pytest.mark.parametrize("fixture,count", [("lp_100_500_seed0.npz", 256), ("lp_500_2000_seed0.npz", 48)])
+def test_every_benchmark_instance_bit_exact_to_convergence(fixture, count):
+    """Not three spot checks: EVERY instance of the headline batch (and the first 48 of the config-4 batch) solved to convergence by the
+    HIP kernel equals the oracle bit for bit -- return code, outer and PCG iteration counts, final iterate, objective, binary solution.
+    The oracle solves run on the host cores in parallel (about 1.5 million oracle iterations for the headline batch)."""
+    from concurrent.futures import ProcessPoolExecutor
+    from lpbox_hip.lp import LpBatch
+    insts = lp_instances(fixture)[:count]
+    B = LpBatch(insts)
+    B.solve_init()
+    rets = B.solve_iter(0, 20000)
+    cfg = B.config()
+    jobs = [(I, cfg["threads"], cfg["threads"] * cfg["elems_per_thread"], B.layout(i), B.row_split(i), B.col_split(i)) for i, I in enumerate(insts)]
+    with ProcessPoolExecutor(min(16, os.cpu_count() or 1)) as ex:
+        res = list(ex.map(_oracle_full_solve, jobs, chunksize=2))
+    for i, (ret, outer, pcg, obj, x, xs) in enumerate(res):
+        assert int(rets[i]) == ret and B.counters(i) == (outer, pcg), i
+        assert bits_equal(B.debug_vec("x", i), x) and B.cal_obj(i) == obj, i
+        assert np.array_equal(B.get_x_sol(i).ravel(), xs), i
