@@ -115,3 +115,19 @@ def test_two_and_four_slot_variants_bit_exact(n, seed):
         if num <= 10:
             num = 0
     assert g.cal_Obj() == o.cal_Obj() and g.get_n() == o.get_n()
+
+
+def test_mixed_size_batch_bit_exact():
+    """One batch holding instances of very different sizes (n = 60 next to n = 500): the common layout has many empty positions for the
+    small ones (quads of holes, helper lanes without a column); each instance still equals its oracle bit for bit."""
+    from lpbox_hip.lp import LpBatch
+    small, big = lp_instances("lp_20_60_seed0.npz"), lp_instances("lp_100_500_seed0.npz")
+    insts = [small[0], big[3], small[5], big[200], small[2]]
+    B = LpBatch(insts)
+    B.solve_init()
+    rets = B.solve_iter(0, 3000)
+    for i, I in enumerate(insts):
+        o = oracle_for(B, i, I)
+        assert int(rets[i]) == o.solve_iter(0, 3000), i
+        assert B.counters(i) == (o.total_outer_iters, o.total_pcg_iters), i
+        assert bits_equal(B.debug_vec("x", i), o.vec("x")) and B.cal_obj(i) == o.cal_Obj(), i
