@@ -60,6 +60,8 @@ struct LpInstance {
     std::vector<int> rowG;             // lanes that share the sum of row r (1,2,4,8)
     std::vector<int> col_own;          // entries of column j summed by its own lane (= its length unless the column is split)
     std::vector<int> col_help;         // [4*j + q]: entries of column j summed by lane q of its quad as a helper (0 = none)
+    std::vector<int> dir_g;            // direct x-update: dense index of row r among the G rows, -1 = D row (lpbox_set_x_update)
+    int nG = 0;
     struct Help { int var, first, count; };
     std::vector<Help> help_of_pos;     // storage position -> helper chunk (var < 0: none)
     std::vector<double> b, f_org;
@@ -95,14 +97,19 @@ struct lpbox_solver {
     bool finalized = false, inited = false;
     int NS = 0, LS = 0, ZS = 0, T = 0, EPT = 0;
     bool colsplit = false;
-    size_t lds = 0;
+    bool identity_rows = true;   // row storage index == row id (bank-aware placement off)
+    bool direct = false;          // opt-in direct x-update (lpbox_set_x_update)
+    int HL = 0, HLD = 0;
+    size_t lds = 0, lds_direct = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double kernel_ms = 0.0;
     long long launches = 0;
     DevBuf<int> rs_ptr, cs_ptr, hs_ptr, isc, ctl, left_idx, xi_rows;
     DevBuf<uint16_t> rs_col, cs_row, rid, rmeta, rgl, cmeta;
-    DevBuf<double> x, z1, z2, b, pd, z4, f, f_org, dsc, hist, dctl, c1_init, xhist, xi_out;
+    DevBuf<int16_t> rdir;
+    DevBuf<int> dng;
+    DevBuf<double> x, z1, z2, b, pd, z4, f, f_org, dsc, hist, dctl, c1_init, xhist, xi_out, Hinv;
     DevBuf<uint8_t> live, newfix, live_init;
     DevBuf<unsigned long long> stamps;
     int ws_cap = 0;        // columns of the current xhist staging buffer
@@ -121,6 +128,7 @@ struct lpbox_solver {
         d.x = x.p; d.z1 = z1.p; d.z2 = z2.p; d.b = b.p; d.pd = pd.p; d.live = live.p; d.newfix = newfix.p;
         d.z4 = z4.p; d.f = f.p; d.dsc = dsc.p; d.isc = isc.p; d.hist = hist.p;
         d.ctl = ctl.p; d.dctl = dctl.p; d.xhist = xhist.p; d.ws_cap = ws_cap; d.stamps = stamps.p;
+        d.H = direct ? Hinv.p : nullptr; d.HL = direct ? HL : 0; d.HLD = direct ? HLD : 0; d.rdir = rdir.p; d.dng = dng.p;
         return d;
     }
 };
@@ -380,6 +388,7 @@ int finalize(lpbox_t *h) {
         std::vector<int> rpos(I.l);
         for (int r = 0; r < I.l; r++) rpos[r] = r;
         if (!nosort && !noconflict) {
+            h->identity_rows = false;
             int max_col = 1;
             for (int j = 0; j < I.n; j++) max_col = std::max(max_col, I.colptr[j + 1] - I.colptr[j]);
             const int ngrp = (int)NS / 32, cap = (int)LS / 32;
@@ -469,7 +478,7 @@ int finalize(lpbox_t *h) {
 
 int run_window(lpbox_t *h, int iter_start, int iter_end, int l2f) {
     HIPCHK(hipEventRecord(h->ev0, h->stream));
-    HIPCHK(lp_launch_window(h->dev(), h->T, h->EPT, h->lds, iter_start, iter_end, l2f, h->stream));
+    HIPCHK(lp_launch_window(h->dev(), h->T, h->EPT, h->direct ? h->lds_direct : h->lds, iter_start, iter_end, l2f, h->stream, h->direct));
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     int rc = refresh_scalars(h);     // synchronises the stream
     if (rc) return rc;
@@ -580,7 +589,7 @@ void lpbox_destroy(lpbox_t *h) {
     h->rs_col.release(); h->cs_row.release(); h->rid.release(); h->rmeta.release(); h->rgl.release(); h->live_init.release();
     h->x.release(); h->z1.release(); h->z2.release(); h->b.release(); h->pd.release(); h->z4.release(); h->f.release();
     h->f_org.release(); h->dsc.release(); h->hist.release(); h->dctl.release(); h->c1_init.release(); h->xhist.release();
-    h->xi_out.release(); h->live.release(); h->newfix.release(); h->stamps.release();
+    h->xi_out.release(); h->live.release(); h->newfix.release(); h->stamps.release(); h->Hinv.release(); h->rdir.release(); h->dng.release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -801,6 +810,66 @@ int lpbox_iterate_l2f(lpbox_t *h, int iter_start, int iter_end, const double *ve
         if (rets) rets[i] = h->h_isc[i * NI_COUNT + NI_RET];
     }
     return h->h_isc[NI_RET];
+}
+
+int lpbox_set_x_update(lpbox_t *h, int mode) {
+    if (valid_handle(h) && h->seg) return fail(LPBOX_E_STATE, "this entry point belongs to the LP flavour");
+    if (!valid_handle(h)) return fail(LPBOX_E_BADHANDLE, "bad handle");
+    if (mode != LPBOX_XUPDATE_PCG && mode != LPBOX_XUPDATE_DIRECT) return fail(LPBOX_E_BADARG, "x-update mode %d", mode);
+    if (mode == LPBOX_XUPDATE_PCG) { h->direct = false; return LPBOX_OK; }
+    int rc = finalize(h);              // the geometry decides whether the dense inverse fits
+    if (rc) return rc;
+    rc = use_device(h);
+    if (rc) return rc;
+    if (!lp_direct_supported(h->T, h->EPT))
+        return fail(LPBOX_E_UNSUPPORTED, "direct x-update needs n <= 512 (this batch: %d threads x %d slots)", h->T, h->EPT);
+    if (!h->identity_rows) return fail(LPBOX_E_UNSUPPORTED, "direct x-update needs the plain row placement (unset LPBOX_LP_BANKAWARE)");
+    if (!h->Hinv.p) {
+        // Rows with pairwise disjoint columns (D) are inverted in closed form, the rest (G) through a dense |G| x |G| inverse in LDS.
+        // Greedy choice of D: rows by ascending length (the XOR "dummy item" rows of an auction are short and mutually disjoint).
+        const size_t B = h->B, NS = h->NS;
+        int gmax = 0;
+        for (auto &I : h->inst) {
+            std::vector<int> order(I.l), used(I.n, 0);
+            for (int r = 0; r < I.l; r++) order[r] = r;
+            std::stable_sort(order.begin(), order.end(), [&](int a, int c) { return I.rowptr[a + 1] - I.rowptr[a] < I.rowptr[c + 1] - I.rowptr[c]; });
+            std::vector<char> isD(I.l, 0);
+            for (int r : order) {
+                bool disjoint = true;
+                for (int e = I.rowptr[r]; e < I.rowptr[r + 1] && disjoint; e++) disjoint = !used[I.colidx[e]];
+                if (!disjoint) continue;
+                isD[r] = 1;
+                for (int e = I.rowptr[r]; e < I.rowptr[r + 1]; e++) used[I.colidx[e]] = 1;
+            }
+            I.dir_g.assign(I.l, -1);
+            I.nG = 0;
+            for (int r = 0; r < I.l; r++) if (!isD[r]) I.dir_g[r] = I.nG++;
+            gmax = std::max(gmax, I.nG);
+        }
+        if (gmax > 128) return fail(LPBOX_E_UNSUPPORTED, "direct x-update: %d rows of E share columns (at most 128 fit the on-chip inverse)", gmax);
+        // pitch = 4 (mod 32) doubles: the quads of a half-wave (8 rows x 4 consecutive columns) fall on 64 distinct LDS banks
+        h->HL = std::max(gmax, 1); h->HLD = ((h->HL + 27) / 32) * 32 + 4;
+        h->lds_direct = lp_window_lds_bytes(h->T, h->NS, h->LS, h->ZS, h->HL, h->HLD);
+        if (h->lds_direct > 160 * 1024)
+            return fail(LPBOX_E_UNSUPPORTED, "direct x-update needs %zu B of LDS (> 160 KiB per CU)", h->lds_direct);
+        std::vector<uint16_t> h_rid(B * NS);
+        HIPCHK(hipMemcpy(h_rid.data(), h->rid.p, h_rid.size() * sizeof(uint16_t), hipMemcpyDeviceToHost));
+        std::vector<int16_t> h_rdir(B * NS, -1);
+        std::vector<int> h_ng(B, 0);
+        for (size_t i = 0; i < B; i++) {
+            const LpInstance &I = h->inst[i];
+            h_ng[i] = I.nG;
+            for (size_t p = 0; p < NS; p++) { const int r = h_rid[i * NS + p]; if (r != 0xFFFF && r < I.l) h_rdir[i * NS + p] = (int16_t)I.dir_g[r]; }
+        }
+        HIPCHK(h->rdir.alloc(B * NS)); HIPCHK(h->dng.alloc(B));
+        HIPCHK(hipMemcpy(h->rdir.p, h_rdir.data(), h_rdir.size() * sizeof(int16_t), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->dng.p, h_ng.data(), h_ng.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(h->Hinv.alloc(B * ((size_t)h->HL * h->HLD + h->LS)));
+    }
+    // the saved inverses belong to whatever ran before: every instance rebuilds its own at its next x-update
+    HIPCHK(hipMemset2DAsync(h->isc.p + NI_H_VALID, NI_COUNT * sizeof(int), 0, sizeof(int), (size_t)h->B, h->stream));
+    h->direct = true;
+    return LPBOX_OK;
 }
 
 int lpbox_set_record(lpbox_t *h, int on) {
@@ -1077,6 +1146,16 @@ int lpbox_get_col_split(lpbox_t *h, int idx, int *own, int *help4) {
     for (int j = 0; j < I.n; j++) own[j] = I.col_own[j];
     for (int k = 0; k < 4 * I.n; k++) help4[k] = I.col_help[k];
     return I.n;
+}
+
+int lpbox_get_direct_rows(lpbox_t *h, int idx, int *gidx_of_row) {
+    int rc = check_idx(h, idx);
+    if (rc) return rc;
+    if (h->seg) return fail(LPBOX_E_STATE, "this entry point belongs to the LP flavour");
+    const LpInstance &I = h->inst[idx];
+    if ((int)I.dir_g.size() != I.l) return fail(LPBOX_E_STATE, "lpbox_set_x_update(LPBOX_XUPDATE_DIRECT) has not been called");
+    for (int r = 0; r < I.l; r++) gidx_of_row[r] = I.dir_g[r];
+    return I.nG;
 }
 
 int lpbox_get_counters(lpbox_t *h, int idx, long long *outer_iters, long long *pcg_iters) {

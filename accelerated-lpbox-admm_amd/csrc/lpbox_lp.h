@@ -37,7 +37,7 @@ enum {
 enum {
     NI_N = 0, NI_L, NI_NNZ, NI_NLIVE, NI_RHO_UPDATED, NI_ITER, NI_HIST_N, NI_RET, NI_STOP,
     NI_PCG_TOTAL, NI_OUTER_TOTAL, NI_LAST_PCG, NI_PLAIN_ITER_P1, NI_APPLY_FIX, NI_FIX_NUM, NI_ACTIVE,
-    NI_EXPR_READY,
+    NI_EXPR_READY, NI_H_VALID,
     NI_COUNT = 24
 };
 // stop reasons
@@ -65,14 +65,20 @@ struct LpBatchDev {
     const int *ctl; const double *dctl;
     // l2f iterate window: xhist[(inst*ws_cap + c)*NS + pos]
     double *xhist; int ws_cap;
+    // opt-in DIRECT x-update (lpbox_set_x_update): H = (c I + E E^T)^-1 per instance, HL rows of pitch HLD, saved
+    // here between launches (the kernel works on an LDS copy); nullptr / 0 in the default PCG mode
+    double *H; int HL, HLD;       // per instance: HL x HLD doubles of H, then LS doubles of W (by row storage index)
+    const int16_t *rdir;          // row-task slot -> dense index of its row among the G rows, -1 = D row
+    const int *dng;               // G rows per instance
     unsigned long long *stamps;   // diagnostic build only (LPBOX_STAMPS): 16 phase counters per instance, else nullptr
 };
 
 // launchers (lpbox_lp_kernels.hip)
-size_t lp_window_lds_bytes(int T, int NS, int LS, int ZS);
+size_t lp_window_lds_bytes(int T, int NS, int LS, int ZS, int HL = 0, int HLD = 0);   // HL > 0: with the direct mode's dense inverse
 hipError_t lp_launch_init(const LpBatchDev &bd, int T, int EPT, const double *f_org, const double *c1_init,
                           const uint8_t *live_init, hipStream_t s);
 hipError_t lp_launch_window(const LpBatchDev &bd, int T, int EPT, size_t lds, int iter_start, int iter_end, int l2f,
-                            hipStream_t s);
+                            hipStream_t s, bool direct = false);
+bool lp_direct_supported(int T, int EPT);      // geometries the DIRECT variant is compiled for
 hipError_t lp_launch_pack_xiters(const LpBatchDev &bd, const int *live_pos, const int *rows, int ws, double *out,
                                  long out_stride, hipStream_t s);

@@ -46,8 +46,8 @@ namespace {
 // LDS carve-up shared by the launcher (size) and the kernel (pointers)
 // ------------------------------------------------------------------------------------------------
 struct LdsLayout {
-    size_t gx, gl, red, hist, rowf, rowy3, rs_ptr, cs_ptr, hs_ptr, rs_col, cs_row, total;
-    __host__ __device__ LdsLayout(int NS, int LS, int ZS, bool lean) {
+    size_t gx, gl, red, hist, rowf, rowy3, rs_ptr, cs_ptr, hs_ptr, rs_col, cs_row, H, dcol, drow, dmap, total;
+    __host__ __device__ LdsLayout(int NS, int LS, int ZS, bool lean, int HL = 0, int HLD = 0) {
         size_t o = 0;
         auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 15) & ~size_t(15); return at; };
         gx = take(sizeof(double) * ((size_t)NS + 1));     // + zero slot at [NS]
@@ -61,6 +61,11 @@ struct LdsLayout {
         hs_ptr = take(sizeof(int) * ((size_t)NS + 1));
         rs_col = take(sizeof(uint16_t) * (size_t)ZS);
         cs_row = take(sizeof(uint16_t) * (size_t)ZS);
+        // direct x-update only (HL > 0): the dense inverse and the pivot column / row of its Gauss-Jordan build
+        H = take(sizeof(double) * (size_t)HL * (size_t)HLD);
+        dcol = take(HL ? sizeof(double) * ((size_t)HL + 1) : 0);
+        drow = take(HL ? sizeof(double) * ((size_t)HL + 1) : 0);
+        dmap = take(HL ? sizeof(int) * ((size_t)HL + 1) : 0);     // dense index of a G row -> its storage index
         total = o;
     }
 };
@@ -311,7 +316,7 @@ __global__ void __launch_bounds__(T) lp_init_kernel(LpBatchDev bd, const double 
         isc[NI_RHO_UPDATED] = 1;                     // LPh:214
         isc[NI_ITER] = 0; isc[NI_HIST_N] = 0; isc[NI_RET] = 0; isc[NI_STOP] = 0;
         isc[NI_PCG_TOTAL] = 0; isc[NI_OUTER_TOTAL] = 0; isc[NI_LAST_PCG] = 0; isc[NI_PLAIN_ITER_P1] = 0;
-        isc[NI_EXPR_READY] = 0;
+        isc[NI_EXPR_READY] = 0; isc[NI_H_VALID] = 0;
         for (int k = 0; k < LP_HIST; k++) bd.hist[(size_t)inst * LP_HIST + k] = 0.0;
     }
 }
@@ -365,7 +370,7 @@ struct RowVec {
     }
 };
 
-template <int T, int EPT, typename RCAPS, typename CCAPS, typename HCAPS>
+template <int T, int EPT, typename RCAPS, typename CCAPS, typename HCAPS, bool DIRECT = false>
 __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_start, int iter_end, int mode) {
     const int l2f = mode & 1, rec = mode & 2;     // rec: keep x after every iteration in xhist (x_iters of the l2f loop; print_fix_info 2/3 of the plain loop)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -377,7 +382,8 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
     const int nnz = isc[NI_NNZ];
     const size_t on = (size_t)inst * bd.NS, ol = (size_t)inst * bd.LS, oz = (size_t)inst * bd.ZS;
 
-    const LdsLayout L(bd.NS, bd.LS, bd.ZS, EPT >= 4);
+    static_assert(!DIRECT || EPT == 1, "the direct x-update is built for the one-slot variants");
+    const LdsLayout L(bd.NS, bd.LS, bd.ZS, EPT >= 4, DIRECT ? bd.HL : 0, DIRECT ? bd.HLD : 0);
     double *gx = (double *)(smem + L.gx);
     double *gl = (double *)(smem + L.gl);       // gl[3*i + c]: c = 0: q = E*p / f - y3, 1: z4, 2: E*y1
     double *red = (double *)(smem + L.red);
@@ -397,6 +403,15 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
         const uint16_t *c0 = bd.rs_col + oz, *r0 = bd.cs_row + oz;
         for (int k = tid; k < nnz; k += T) { s_rs_col[k] = c0[k]; s_cs_row[k] = r0[k]; }
         if (tid == 0) { gx[bd.NS] = 0.0; gl[3 * bd.LS] = 0.0; gl[3 * bd.LS + 1] = 0.0; gl[3 * bd.LS + 2] = 0.0; }   // zero slots
+    }
+    // ---- direct x-update: the dense inverse H, kept in LDS for the launch (section 17 of DESIGN.md) ----
+    double *Hm = (double *)(smem + L.H), *dcol = (double *)(smem + L.dcol), *drow = (double *)(smem + L.drow);
+    int *dmap = (int *)(smem + L.dmap);
+    int h_valid = 0;
+    if constexpr (DIRECT) {
+        h_valid = isc[NI_H_VALID];
+        const size_t hsz = (size_t)bd.HL * bd.HLD;
+        if (h_valid) { const double *Hg = bd.H + (size_t)inst * (hsz + bd.LS); for (size_t e = tid; e < hsz; e += T) Hm[e] = Hg[e]; }
     }
 
     // ---- per-thread state ----
@@ -438,6 +453,18 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
         f.set(s, rgl(s), leader, leader ? bd.f[ol + rid] : 0.0);
         y3.set(s, rgl(s), leader, 0.0);
         Ex[s] = 0.0;
+    }
+    // direct x-update: class of this lane's row (dense index among the G rows, -1 = a D row: its columns meet no other D row) and the
+    // D row's weight 1 / (c + live variables in the row)
+    int gdir = -1;
+    double wrow = 0.0;
+    if constexpr (DIRECT) {
+        if (rvalid(0)) {
+            gdir = bd.rdir[on + tid];
+            if (gdir >= 0) dmap[gdir] = rgl(0);
+            if (h_valid) wrow = bd.H[(size_t)inst * ((size_t)bd.HL * bd.HLD + bd.LS) + (size_t)bd.HL * bd.HLD + rgl(0)];
+            gl[3 * rgl(0) + 2] = 0.0;
+        }
     }
     double rho1 = dsc[ND_RHO1], rho2 = dsc[ND_RHO2], rho4 = dsc[ND_RHO4];
     double prev_rho1 = dsc[ND_PREV_RHO1], prev_rho2 = dsc[ND_PREV_RHO2], prev_rho4 = dsc[ND_PREV_RHO4];
@@ -590,6 +617,7 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
             for (int s = 0; s < EPT; s++) { double v = dI; v += rho4 * Esq(s); pd.set(s, v); }
             r4Et = rho4;
             expr_ready = 1;
+            h_valid = 0;                                             // direct mode: E lost columns, the inverse is rebuilt
         }
     }
 
@@ -670,13 +698,13 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
                 r_ -= tB;
                 rhs[s] = r_;
             }
-            {
+            if constexpr (!DIRECT) {
                 double q[EPT];
                 rows_gather(q);
 #pragma unroll
                 for (int s = 0; s < EPT; s++) if (rvalid(s)) gl[3 * rgl(s) + 2] = q[s];
+                __syncthreads();
             }
-            __syncthreads();
             if (rhoUpdated) {                                         // DiagonalPreconditioner::compute (:883-890)
 #pragma unroll
                 for (int s = 0; s < EPT; s++) { const double v = pd.get(s); dinv[s] = (v != 0.0) ? 1.0 / v : 1.0; }
@@ -684,7 +712,102 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
             }
             STAMP(1)
             // ---------------- PCG (LPcpp:251-335) on (dI*I + rho4 E^T E) x = rhs ----------------
-            double xt[EPT], r[EPT], p[EPT];
+            double xt[EPT];
+            int k_it = 0;
+            bool pcg_fail = false;
+            if constexpr (DIRECT) {
+                // ---------------- DIRECT x-update (opt-in, NOT the reference's PCG) ----------------
+                // (a I + r E^T E) x = rhs, a = dI, r = r4Et, solved exactly.  Rows of E: D rows (pairwise disjoint columns, chosen by the
+                // host) and G rows (the rest, dense index gdir).  a I + r E_D^T E_D is block diagonal with blocks a I + r 1 1^T: its
+                // inverse is Q / a, Q v = v - E_D^T W E_D v, W = diag(1 / (c + m_i)), c = a / r.  Woodbury over the G rows:
+                //     x = Q (rhs - E_G^T H E_G Q rhs) / a,   H = (c I + E_G Q E_G^T)^-1  (|G| x |G|, in LDS).
+                // c is constant while rho1, rho2, rho4 are scaled together (LPcpp:951-970): H and W are built once per instance and fix.
+                const int nG = bd.dng[inst], HLD = bd.HLD;
+                // Q v for this thread's variable: sigma = E v by rows, D rows publish w * sigma (G rows 0), the column sum picks it up
+                auto apply_Q = [&](double vin) {
+                    gx[tid] = live[0] ? vin : 0.0;
+                    __syncthreads();
+                    double sg[EPT], cs[EPT];
+                    rows_gather(sg);
+                    if (rvalid(0)) gl[3 * rgl(0)] = gdir < 0 ? wrow * sg[0] : 0.0;
+                    __syncthreads();
+                    cols_gather(std::integral_constant<int, 0>{}, op_add, cs);
+                    return vin - cs[0];
+                };
+                if (!h_valid) {
+                    const double cdiag = dI / r4Et;
+                    {
+                        gx[tid] = live[0] ? 1.0 : 0.0;
+                        __syncthreads();
+                        double cnt[EPT];
+                        rows_gather(cnt);                                     // m_i
+                        wrow = 1.0 / (cdiag + cnt[0]);
+                    }
+                    for (int e = tid; e < bd.HL * HLD; e += T) Hm[e] = 0.0;
+                    for (int bcol = 0; bcol < nG; bcol++) {                   // column bcol of c I + E_G Q E_G^T
+                        if (rvalid(0) && gdir >= 0) gl[3 * rgl(0) + 2] = (gdir == bcol) ? 1.0 : 0.0;
+                        __syncthreads();
+                        double w[EPT], g[EPT];
+                        cols_gather(std::integral_constant<int, 2>{}, op_add, w);
+                        const double qw = apply_Q(w[0]);
+                        gx[tid] = live[0] ? qw : 0.0;
+                        __syncthreads();
+                        rows_gather(g);
+                        if (rvalid(0) && gdir >= 0) Hm[gdir * HLD + bcol] = (gdir == bcol) ? g[0] + cdiag : g[0];
+                    }
+                    __syncthreads();
+                    // in-place Gauss-Jordan without pivoting (SPD): step k scales row k by the reciprocal pivot, every other element
+                    // loses (its column-k entry) x (scaled row k), column k becomes -(entry x reciprocal pivot)
+                    for (int k = 0; k < nG; k++) {
+                        const double piv = 1.0 / Hm[k * HLD + k];
+                        if (tid < nG) { dcol[tid] = Hm[tid * HLD + k]; drow[tid] = tid == k ? piv : Hm[k * HLD + tid] * piv; }
+                        __syncthreads();
+                        {
+                            const int j = tid & 127;
+                            if (j < nG) {
+                                const double rk = drow[j];
+                                for (int i = tid >> 7; i < nG; i += T / 128) {
+                                    const double ck = dcol[i];
+                                    const double cur = Hm[i * HLD + j];
+                                    Hm[i * HLD + j] = i == k ? rk : (j == k ? -(ck * piv) : cur - ck * rk);
+                                }
+                            }
+                        }
+                        __syncthreads();
+                    }
+                    {
+                        double *Hg = bd.H + (size_t)inst * ((size_t)bd.HL * HLD + bd.LS);
+                        for (int e = tid; e < bd.HL * HLD; e += T) Hg[e] = Hm[e];
+                        if (rvalid(0)) Hg[(size_t)bd.HL * HLD + rgl(0)] = wrow;
+                    }
+                    h_valid = 1;
+                }
+                const double q1 = apply_Q(rhs[0]);
+                gx[tid] = live[0] ? q1 : 0.0;
+                __syncthreads();
+                {
+                    double t[EPT];
+                    rows_gather(t);                                           // t = E_G Q rhs
+                    if (rvalid(0) && gdir >= 0) dcol[gdir] = t[0];
+                }
+                __syncthreads();
+                // u = H t: the four lanes of a quad share a G row, lane q adds the columns j = q, q + 4, ... in ascending order,
+                // the partials combine as (p0 + p1) + (p2 + p3)
+                for (int i = tid >> 2; i < nG; i += T / 4) {
+                    const double *Hr = Hm + i * HLD;
+                    double acc = 0.0;
+#pragma unroll 4
+                    for (int j = tid & 3; j < nG; j += 4) acc = acc + Hr[j] * dcol[j];
+                    const double u = quad_sum(acc);
+                    if ((tid & 3) == 0) gl[3 * dmap[i] + 2] = u;
+                }
+                __syncthreads();
+                double v[EPT];
+                cols_gather(std::integral_constant<int, 2>{}, op_add, v);    // v = E_G^T u (the D rows hold 0)
+                const double yv = rhs[0] - v[0];
+                xt[0] = apply_Q(yv) / dI;
+            } else {
+            double r[EPT], p[EPT];
             double p3[3] = {0.0, 0.0, 0.0};
             double tcol[EPT];
             cols_gather(std::integral_constant<int, 2>{}, op_scaled, tcol);
@@ -705,8 +828,6 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
             STAMP(2)
             const double rhsNorm2 = p3[0];
             double residualNorm2 = p3[1], absNew = p3[2];
-            int k_it = 0;
-            bool pcg_fail = false;
             if (rhsNorm2 == 0) {                                      // :273-278
 #pragma unroll
                 for (int s = 0; s < EPT; s++) xt[s] = 0.0;
@@ -794,6 +915,7 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
                     }
                 }
             }
+            }   // PCG
             STAMP(11)
             last_pcg = k_it;
             pcg_total += k_it;
@@ -949,6 +1071,7 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
         isc[NI_RET] = ret; isc[NI_STOP] = stop;
         isc[NI_PCG_TOTAL] = pcg_total; isc[NI_OUTER_TOTAL] = outer_total; isc[NI_LAST_PCG] = last_pcg;
         isc[NI_EXPR_READY] = expr_ready;
+        if constexpr (DIRECT) isc[NI_H_VALID] = h_valid;
         if (l2f) isc[NI_ITER] = it;                                   // member `iter` (LPh:279), advanced by l2f only
         else isc[NI_PLAIN_ITER_P1] = it + 1;                          // LPcpp:1081
         for (int k = 0; k < LP_HIST; k++) bd.hist[(size_t)inst * LP_HIST + k] = LEAN ? s_hist[hbuf * LP_HIST + k] : h_reg[LEAN ? 0 : k];
@@ -976,9 +1099,11 @@ __global__ void lp_pack_xiters_kernel(LpBatchDev bd, const int *live_pos, const 
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
-size_t lp_window_lds_bytes(int T, int NS, int LS, int ZS) {
-    return LdsLayout(NS, LS, ZS, NS / T >= 4).total;
+size_t lp_window_lds_bytes(int T, int NS, int LS, int ZS, int HL, int HLD) {
+    return LdsLayout(NS, LS, ZS, NS / T >= 4, HL, HLD).total;
 }
+
+bool lp_direct_supported(int T, int EPT) { return (T == 512 || T == 256) && EPT == 1; }
 
 // (threads, slots per thread) -> per-slot register capacities of the row-task / column gather lists.
 #define LP_DISPATCH(KERNEL_CALL)                                                                                                          \
@@ -1003,7 +1128,20 @@ hipError_t lp_launch_init(const LpBatchDev &bd, int T, int EPT, const double *f_
 }
 
 hipError_t lp_launch_window(const LpBatchDev &bd, int T, int EPT, size_t lds, int iter_start, int iter_end, int l2f,
-                            hipStream_t s) {
+                            hipStream_t s, bool direct) {
+    if (direct) {
+        if (!lp_direct_supported(T, EPT) || bd.H == nullptr || bd.HL <= 0 || bd.HL > 128) return hipErrorInvalidConfiguration;
+#define CALL_DIRECT(TT)                                                                                        \
+    {                                                                                                          \
+        auto kfn = lp_window_kernel<TT, 1, Caps<12>, Caps<12>, Caps<8>, true>;                                 \
+        hipError_t e = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e != hipSuccess) return e;                                                                         \
+        hipLaunchKernelGGL(kfn, dim3(bd.B), dim3(TT), lds, s, bd, iter_start, iter_end, l2f);                  \
+    }
+        if (T == 512) CALL_DIRECT(512) else CALL_DIRECT(256)
+#undef CALL_DIRECT
+        return hipGetLastError();
+    }
 #define CALL_WIN(TT, EE, RR, CCC, HHH)                                                                             \
     {                                                                                                          \
         auto kfn = lp_window_kernel<TT, EE, LP_UNPAREN RR, LP_UNPAREN CCC, LP_UNPAREN HHH>;                                    \

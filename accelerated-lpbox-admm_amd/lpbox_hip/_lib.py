@@ -39,6 +39,8 @@ SYMBOLS = {
     "lpbox_get_iter": (C.c_int, [C.c_void_p, C.c_int]),
     "lpbox_get_x_iters": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "lpbox_set_record": (C.c_int, [C.c_void_p, C.c_int]),
+    "lpbox_set_x_update": (C.c_int, [C.c_void_p, C.c_int]),
+    "lpbox_get_direct_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "lpbox_seg_get_x_history": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "lpbox_policy_layout": (C.c_int, [C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
     "lpbox_policy_encode_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

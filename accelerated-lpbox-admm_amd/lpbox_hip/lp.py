@@ -91,6 +91,21 @@ class LpBatch:
         get_x_iters_2d(j - i)."""
         check(self._L.lpbox_set_record(self._h, 1 if on else 0), "lpbox_set_record")
 
+    def set_x_update(self, mode="pcg"):
+        """How the x-update solves its linear system.  "pcg" (default) is the reference's Jacobi-PCG to 1e-3 (LPcpp:251-335, :894) and
+        the only mode that reproduces the reference's iterates.  "direct" is an opt-in WITHOUT reference counterpart: an exact solve
+        through a dense l x l inverse kept on chip -- several times faster per ADMM iteration, different
+        iterates / iteration counts; raises for batches it does not fit (n <= 512, at most 128 rows sharing columns)."""
+        if mode not in ("pcg", "direct"):
+            raise ValueError("x-update mode must be 'pcg' or 'direct'")
+        check(self._L.lpbox_set_x_update(self._h, 1 if mode == "direct" else 0), "lpbox_set_x_update")
+
+    def direct_rows(self, idx=0):
+        """Row split of the direct x-update (lpbox_get_direct_rows): dense index per row of E, -1 = closed-form row."""
+        out = np.zeros(self.get_l(idx), np.int32)
+        check(self._L.lpbox_get_direct_rows(self._h, idx, out.ctypes.data_as(C.c_void_p)), "lpbox_get_direct_rows")
+        return out
+
     def solve_iter(self, i, j):
         rets = np.zeros(self.B, np.int32)
         check(self._L.lpbox_iterate(self._h, _as_int(i, "i"), _as_int(j, "j"), rets.ctypes.data_as(C.c_void_p)),

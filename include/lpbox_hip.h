@@ -88,6 +88,18 @@ int lpbox_get_x_iters(lpbox_t *h, int idx, int ws, double *out);
  * call, exactly like the x_iters window of the l2f loop) and lpbox_get_x_iters / _device hand them out; the CSV itself is written by the
  * host wrapper.  Off by default. */
 int lpbox_set_record(lpbox_t *h, int on);
+/* LP flavour, OPT-IN and without a reference counterpart: how the x-update solves ((rho1+rho2) I + rho4 E^T E) x = rhs (the system of
+ * LPcpp:872-894).  LPBOX_XUPDATE_PCG (default) = the reference's Jacobi-PCG to 1e-3 (LPcpp:251-335), bit-exact against the oracle of the
+ * reference's algorithm.  LPBOX_XUPDATE_DIRECT = an exact solve through the Woodbury identity with a dense l x l inverse kept in LDS
+ * (DESIGN.md section 17): a different (more accurate) x-update, hence different iterates and iteration counts than the reference's;
+ * available for n <= 512 with at most 128 rows of E that share columns with other rows (the XOR rows of an auction do not).  May be switched between calls; returns LPBOX_E_UNSUPPORTED when the batch does not fit. */
+#define LPBOX_XUPDATE_PCG 0
+#define LPBOX_XUPDATE_DIRECT 1
+int lpbox_set_x_update(lpbox_t *h, int mode);
+/* The row split of the direct mode for instance idx (the order of its arithmetic; tests hand it to the oracle's mirror): gidx_of_row[l] =
+ * dense index of the row among the rows solved through the on-chip inverse, -1 for a row handled in closed form (its columns meet no
+ * other such row).  Returns the number of dense rows. */
+int lpbox_get_direct_rows(lpbox_t *h, int idx, int *gidx_of_row);
 /* Segmentation flavour: with record on (on == 1: up to 2000 iterations, on > 1: that many), lpbox_seg_legacy keeps x_sol of every iteration
  * (print_info 1 -> ../xiter/<problem>.csv, SEGcpp:1209-1213, 1270-1277).  out == NULL: number of iterations recorded; otherwise copies
  * iterations [first, first+count) as count rows of org_n doubles. */

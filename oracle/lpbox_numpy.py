@@ -11,7 +11,10 @@ import scipy.sparse as sp
 
 
 class NumpyLpBox:
-    def __init__(self, n, l, colptr, rowidx, b, f=None):
+    def __init__(self, n, l, colptr, rowidx, b, f=None, x_update="pcg"):
+        # x_update "direct": the HIP kernels' opt-in exact x-update (no reference counterpart), here as a plain dense solve of
+        # (dI I + rho4 E^T E) x = rhs -- none of the Woodbury algebra of the kernel / the C oracle's mirror, so it pins their math
+        self.x_update = x_update
         data = np.ones(len(rowidx))
         self.E = sp.csc_matrix((data, rowidx, colptr), shape=(l, n))
         self.orgE = self.E.copy()
@@ -117,7 +120,12 @@ class NumpyLpBox:
             self.invdiag = np.where(self.pd != 0, 1.0 / self.pd, 1.0)
             self.rhoUpdated = False
         xt = self.y1.copy()
-        cg, k = self._pcg(rhs, xt)
+        if self.x_update == "direct":
+            Ed = self.E.toarray()
+            xt = np.linalg.solve(self.dI * np.eye(self.n) + self.r4Et_scale * (Ed.T @ Ed), rhs)
+            cg, k = 1, 0
+        else:
+            cg, k = self._pcg(rhs, xt)
         self.pcg_trace.append(k)
         if l2f and cg == -1:
             return 2

@@ -187,6 +187,10 @@ struct lpo {
     FILE *log_fp;                  /* does_log (LPh:148, default ON in the reference): the per-iteration text log of ADMM_lp_iters */
     int *orgEr_ptr, *orgEr_col; double *orgEr_val;   /* CSR view of org_E (rows in ascending column order) */
     double *full_v;                /* scratch: a live vector expanded to the original variable order */
+    int x_update;                  /* 0 = the reference's PCG (default); 1 = the kernels' opt-in DIRECT x-update (no reference counterpart) */
+    double *H; int H_valid, H_ld;  /* direct mode: (c I + E E^T)^-1 over the rows of E, row pitch H_ld */
+    double *dt, *du, *dsig, *dw, *dq; /* direct mode scratch and W */
+    int *dir_g, *dgrow, nG;        /* direct mode: dense index of each G row (-1 = D row), its inverse map */
     int has_problem, inited;
 };
 
@@ -299,6 +303,7 @@ void lpo_destroy(lpo_t *o) {
     if (o->log_fp) fclose(o->log_fp);
     free(o->b); free(o->f); free(o->gpu_pos); free(o->row_G); free(o->col_own); free(o->col_help); free(o->valT); free(o->curT);
     free(o->orgEr_ptr); free(o->orgEr_col); free(o->orgEr_val);
+    free(o->H); free(o->dt); free(o->du); free(o->dsig); free(o->dw); free(o->dq); free(o->dir_g); free(o->dgrow);
     free(o);
 }
 
@@ -310,6 +315,13 @@ void lpo_set_order(lpo_t *o, int mode, int T) {
 void lpo_set_verbose(lpo_t *o, int verbose) { o->verbose = verbose; }
 void lpo_set_chunk(lpo_t *o, int chunk) { o->gpu_chunk = chunk > 0 ? chunk : 0; }
 void lpo_set_ranks(lpo_t *o, int ranks) { o->gpu_ranks = ranks > 1 ? ranks : 0; }
+void lpo_set_x_update(lpo_t *o, int mode) { o->x_update = mode == 1 ? 1 : 0; o->H_valid = 0; }
+void lpo_set_direct_rows(lpo_t *o, const int *gidx_of_row, int l) {
+    free(o->dir_g);
+    o->dir_g = (int *)malloc(sizeof(int) * (size_t)(l + 1));
+    memcpy(o->dir_g, gidx_of_row, sizeof(int) * (size_t)l);
+    o->H_valid = 0;
+}
 
 void lpo_set_positions(lpo_t *o, const int *pos_of_var, int n, int npos) {
     free(o->gpu_pos);
@@ -592,6 +604,97 @@ static int conjugate_gradient(lpo_t *o, const double *rhs, double *x, int *iters
     return 1;
 }
 
+
+/* ------------------------------------------------------------------------------------------ */
+/* DIRECT x-update -- NOT the reference's algorithm.  The HIP LP kernel offers it as an opt-in  */
+/* (lpbox_set_x_update): instead of running Jacobi-PCG to 1e-3 on         */
+/*   (a I + r E^T E) x = rhs,  a = rho1 + rho2, r = rho4     (the system of LPcpp:872-894)      */
+/* it solves the system exactly.  The rows of E are split into a set D of rows with pairwise    */
+/* disjoint columns (the XOR "dummy item" rows of a combinatorial auction) and the rest G:      */
+/*   a I + r E_D^T E_D  is block diagonal with blocks a I + r 1 1^T, inverted in closed form:   */
+/*       its inverse is Q / a,  Q v = v - E_D^T W E_D v,  W = diag(1 / (c + m_i)),  c = a / r,  */
+/*       m_i = live variables in row i;                                                         */
+/*   the Woodbury identity over the G rows then gives                                           */
+/*       x = Q (rhs - E_G^T H E_G Q rhs) / a,      H = (c I + E_G Q E_G^T)^-1   (|G| x |G|).     */
+/* c is constant while rho1, rho2, rho4 are scaled together (LPcpp:951-970), so H and W are     */
+/* built once, at the first x-update after init or after a fix, H by in-place Gauss-Jordan      */
+/* without pivoting (the matrix is SPD).  This restatement follows the kernel's operation order */
+/* so that kernel and oracle agree bit for bit; the reference has nothing to compare it with.   */
+/* ------------------------------------------------------------------------------------------ */
+static void direct_Q(lpo_t *o, const double *v, double *out) {       /* out = Q v (vectors over the live variables) */
+    const int l = o->l, n = o->n;
+    double *sig = o->dsig, *cs = o->temp_mm + l;
+    spmv_E(o, v, sig);
+    for (int i = 0; i < l; i++) sig[i] = o->dir_g[i] < 0 ? o->dw[i] * sig[i] : 0.0;
+    spmv_Et(o, &o->Et, sig, cs);
+    for (int j = 0; j < n; j++) out[j] = v[j] - cs[j];
+}
+
+static void direct_build(lpo_t *o) {
+    const int l = o->l, n = o->n;
+    if (!o->dir_g) {                 /* no split given: every row is a G row */
+        o->dir_g = (int *)malloc(sizeof(int) * (size_t)(l + 1));
+        for (int i = 0; i < l; i++) o->dir_g[i] = i;
+    }
+    int nG = 0;
+    for (int i = 0; i < l; i++) if (o->dir_g[i] >= 0) nG++;
+    o->nG = nG;
+    const int ld = o->H_ld = nG + 2;
+    o->H = (double *)realloc(o->H, sizeof(double) * (size_t)ld * (size_t)(nG > 0 ? nG : 1));
+    o->dt = (double *)realloc(o->dt, sizeof(double) * (size_t)(l + 1));
+    o->du = (double *)realloc(o->du, sizeof(double) * (size_t)(l + 1));
+    o->dsig = (double *)realloc(o->dsig, sizeof(double) * (size_t)(l + 1));
+    o->dw = (double *)realloc(o->dw, sizeof(double) * (size_t)(l + 1));
+    o->dq = (double *)realloc(o->dq, sizeof(double) * (size_t)(2 * n + 2));
+    o->dgrow = (int *)realloc(o->dgrow, sizeof(int) * (size_t)(nG + 1));
+    for (int i = 0; i < l; i++) if (o->dir_g[i] >= 0) o->dgrow[o->dir_g[i]] = i;
+    double *H = o->H, *wv = o->dq, *qw = o->dq + n;
+    const double r4 = o->r4Et.nnz > 0 ? o->r4Et.val[0] / o->Et.val[0] : o->rho4;
+    const double c = o->Dd[0] / r4;
+    for (int j = 0; j < n; j++) wv[j] = 1.0;
+    spmv_E(o, wv, o->dsig);                                          /* m_i: live variables of row i */
+    for (int i = 0; i < l; i++) o->dw[i] = 1.0 / (c + o->dsig[i]);
+    for (int b = 0; b < nG; b++) {                                   /* column b of c I + E_G Q E_G^T */
+        for (int i = 0; i < l; i++) o->dt[i] = 0.0;
+        o->dt[o->dgrow[b]] = 1.0;
+        spmv_Et(o, &o->Et, o->dt, wv);
+        direct_Q(o, wv, qw);
+        spmv_E(o, qw, o->du);
+        for (int gi = 0; gi < nG; gi++) H[(size_t)gi * ld + b] = gi == b ? o->du[o->dgrow[gi]] + c : o->du[o->dgrow[gi]];
+    }
+    /* Gauss-Jordan, step k: row k scaled by the reciprocal pivot; every other element G[i][j] -= G[i][k] * G[k][j]; column k last */
+    for (int k = 0; k < nG; k++) {
+        const double piv = 1.0 / H[(size_t)k * ld + k];
+        for (int j = 0; j < nG; j++) if (j != k) H[(size_t)k * ld + j] = H[(size_t)k * ld + j] * piv;
+        for (int i = 0; i < nG; i++) {
+            if (i == k) continue;
+            const double fik = H[(size_t)i * ld + k];
+            for (int j = 0; j < nG; j++) if (j != k) H[(size_t)i * ld + j] = H[(size_t)i * ld + j] - fik * H[(size_t)k * ld + j];
+        }
+        for (int i = 0; i < nG; i++) if (i != k) H[(size_t)i * ld + k] = -(H[(size_t)i * ld + k] * piv);
+        H[(size_t)k * ld + k] = piv;
+    }
+    o->H_valid = 1;
+}
+
+static void direct_solve(lpo_t *o, const double *rhs, double *x) {
+    const int l = o->l, n = o->n, ld = o->H_ld, nG = o->nG;
+    double *q1 = o->dq, *y = o->dq + n, *v = o->temp_mm + l;
+    direct_Q(o, rhs, q1);
+    spmv_E(o, q1, o->dt);                                            /* t = E_G Q rhs (the D rows of the product are not used) */
+    /* u = H t: the four lanes of a quad share a row, lane q adds the columns j = q, q + 4, ... (ascending); (p0 + p1) + (p2 + p3) */
+    for (int i = 0; i < l; i++) o->du[i] = 0.0;
+    for (int gi = 0; gi < nG; gi++) {
+        double part[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int j = 0; j < nG; j++) part[j & 3] = part[j & 3] + o->H[(size_t)gi * ld + j] * o->dt[o->dgrow[j]];
+        o->du[o->dgrow[gi]] = (part[0] + part[1]) + (part[2] + part[3]);
+    }
+    spmv_Et(o, &o->Et, o->du, v);
+    for (int j = 0; j < n; j++) y[j] = rhs[j] - v[j];
+    direct_Q(o, y, q1);
+    for (int j = 0; j < n; j++) x[j] = q1[j] / o->Dd[0];
+}
+
 /* std_dev LPcpp:358-377 */
 static double std_dev(lpo_t *o, const double *arr, size_t begin, size_t end) {
     double mean = 0, std_deviation = 0;
@@ -698,6 +801,7 @@ int lpo_init(lpo_t *o) {
     for (int i = 0; i < n; i++) o->best_sol[i] = o->x[i];         /* :725 */
     o->best_bin_obj = dot_live(o, o->b, o->x);                    /* :727 compute_cost_lp(x_sol, b) = b.dot(x) */
     /* members that keep their in-class initialisers (LPh:213-219,279): only valid for a fresh object */
+    o->H_valid = 0;
     o->inited = 1;
     return 1;
 }
@@ -769,8 +873,16 @@ static int admm_iteration(lpo_t *o, int iter, int iter_start, int l2f, int *ret,
 
     double tol = o->pcg_tol;
     int maxiter = o->pcg_maxiters;
-    int cg;
-    if (!l2f) {
+    int cg = 1;
+    if (o->x_update == 1) {                                    /* opt-in direct x-update (no reference counterpart), see direct_build */
+        if (!o->H_valid) direct_build(o);
+        direct_solve(o, tv, o->x);
+        maxiter = 0;
+        if (l2f) {
+            for (int i = 0; i < n; i++) o->x_iters[(size_t)(*cc) * (size_t)o->xi_rows + (size_t)i] = o->x[i];
+            (*cc)++;
+        }
+    } else if (!l2f) {
         for (int i = 0; i < n; i++) o->x[i] = o->y1[i];         /* :892 x_sol = y1 */
         cg = conjugate_gradient(o, tv, o->x, &maxiter, &tol);   /* :894 (return value ignored) */
         if (cg == -1) o->last_stop = 3;
@@ -998,6 +1110,7 @@ int lpo_iters_l2f(lpo_t *o, int iter_start, int iter_end, const double *vec, int
             memcpy(o->left_idx, new_left, sizeof(int) * (size_t)nk);
             free(new_left);
             o->n = nk;                                       /* (:1295; moved up so the norm below runs on the live set) */
+            o->H_valid = 0;                                  /* direct mode: E changed */
             if (sqrt(sqnorm_live(o, o->x)) < 1e-3) ret = 1;  /* :1223 */
             o->prev_sum = o->sum_fix_obj;                    /* :1247-1250 */
             o->sum_fix_obj += o->fix_obj;

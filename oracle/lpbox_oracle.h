@@ -52,6 +52,11 @@ void lpo_set_col_split(lpo_t *o, const int *own, const int *help4, int n);
 void lpo_set_chunk(lpo_t *o, int chunk);
 /* GPU order of the variable-sharded run: `ranks` contiguous blocks of variables; per-rank sums added in rank order (needs lpo_set_chunk) */
 void lpo_set_ranks(lpo_t *o, int ranks);
+/* 0 = the reference's Jacobi-PCG x-update (default); 1 = the HIP kernels' opt-in DIRECT x-update (Woodbury with a dense l x l inverse;
+ * NOT the reference's algorithm -- mirrored here only so that the kernel mode has a bit-exact checker) */
+void lpo_set_x_update(lpo_t *o, int mode);
+/* direct mode: dense index of every row of E among the G rows, -1 for a D row (include/lpbox_hip.h lpbox_get_direct_rows); never called = all G */
+void lpo_set_direct_rows(lpo_t *o, const int *gidx_of_row, int l);
 /* the reference's default per-iteration text log (does_log, LPh:148; LPcpp:1013-1067) appended to `path`; NULL / "" turns it off (the default here) */
 int lpo_set_log(lpo_t *o, const char *path);
 /* 1 = print the reference's stop messages to stdout (default 0 = quiet). */

@@ -44,6 +44,8 @@ def lib():
     L.lpo_set_verbose.argtypes = [C.c_void_p, C.c_int]
     L.lpo_set_chunk.argtypes = [C.c_void_p, C.c_int]
     L.lpo_set_ranks.argtypes = [C.c_void_p, C.c_int]
+    L.lpo_set_x_update.argtypes = [C.c_void_p, C.c_int]
+    L.lpo_set_direct_rows.argtypes = [C.c_void_p, _ip, C.c_int]
     L.lpo_set_log.argtypes = [C.c_void_p, C.c_char_p]
     L.lpo_set_positions.argtypes = [C.c_void_p, _ip, C.c_int, C.c_int]
     L.lpo_set_row_split.argtypes = [C.c_void_p, _ip, C.c_int]
@@ -81,7 +83,7 @@ def lib():
 class LpOracle:
     """Mirror of the reference's PyLPboxADMMsolver (lpbox.pyx:7-76) on the CPU oracle."""
 
-    def __init__(self, print_info=0, order=ORDER_EIGEN, T=512, verbose=False, positions=None, npos=0, row_split=None, chunk=0, col_split=None, ranks=0):
+    def __init__(self, print_info=0, order=ORDER_EIGEN, T=512, verbose=False, positions=None, npos=0, row_split=None, chunk=0, col_split=None, ranks=0, x_update="pcg", direct_rows=None):
         self.L = lib()
         self.h = C.c_void_p(self.L.lpo_create(int(print_info)))
         self.L.lpo_set_order(self.h, order, T)
@@ -90,6 +92,12 @@ class LpOracle:
             self.L.lpo_set_chunk(self.h, int(chunk))
         if ranks:
             self.L.lpo_set_ranks(self.h, int(ranks))
+        if x_update != "pcg":        # the kernels' opt-in direct x-update (no reference counterpart)
+            assert x_update == "direct"
+            self.L.lpo_set_x_update(self.h, 1)
+            if direct_rows is not None:
+                direct_rows = np.ascontiguousarray(direct_rows, np.int32)
+                self.L.lpo_set_direct_rows(self.h, direct_rows, len(direct_rows))
         if positions is not None:
             positions = np.ascontiguousarray(positions, np.int32)
             self.L.lpo_set_positions(self.h, positions, len(positions), int(npos))
@@ -100,6 +108,14 @@ class LpOracle:
             own = np.ascontiguousarray(col_split[0], np.int32)
             help4 = np.ascontiguousarray(col_split[1], np.int32).ravel()
             self.L.lpo_set_col_split(self.h, own, help4, len(own))
+
+    def set_x_update(self, mode, direct_rows=None):
+        """Switch between the reference's PCG and the kernels' opt-in direct x-update between calls (lpbox_set_x_update)."""
+        assert mode in ("pcg", "direct")
+        self.L.lpo_set_x_update(self.h, 1 if mode == "direct" else 0)
+        if direct_rows is not None:
+            direct_rows = np.ascontiguousarray(direct_rows, np.int32)
+            self.L.lpo_set_direct_rows(self.h, direct_rows, len(direct_rows))
 
     def __del__(self):
         try:

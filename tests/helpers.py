@@ -12,8 +12,9 @@ def lp_instances(name):
     return O.load_lp_batch(os.path.join(GOLDEN, name))
 
 
-def make_oracle(I, order=O.ORDER_EIGEN, T=512, positions=None, npos=0, row_split=None, col_split=None):
-    s = O.LpOracle(0, order=order, T=T, positions=positions, npos=npos, row_split=row_split, col_split=col_split)
+def make_oracle(I, order=O.ORDER_EIGEN, T=512, positions=None, npos=0, row_split=None, col_split=None, x_update="pcg", direct_rows=None):
+    s = O.LpOracle(0, order=order, T=T, positions=positions, npos=npos, row_split=row_split, col_split=col_split, x_update=x_update,
+                   direct_rows=direct_rows)
     s.set_problem(I["n"], I["l"], I["colptr"], I["rowidx"], I["b"], I.get("f"))
     s.solve_init()
     return s
@@ -41,10 +42,10 @@ def oracle_like(g, I):
     return oracle_for(g.batch if hasattr(g, "batch") else g, 0, I)
 
 
-def oracle_for(batch, idx, I):
+def oracle_for(batch, idx, I, x_update="pcg", direct_rows=None):
     cfg = batch.config()
     return make_oracle(I, O.ORDER_GPU, cfg["threads"], batch.layout(idx), cfg["threads"] * cfg["elems_per_thread"],
-                       batch.row_split(idx), batch.col_split(idx))
+                       batch.row_split(idx), batch.col_split(idx), x_update=x_update, direct_rows=direct_rows)
 
 
 # ------------------------------------------------------------------------------------------------
