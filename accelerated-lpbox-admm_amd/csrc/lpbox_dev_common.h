@@ -82,7 +82,7 @@ __device__ __forceinline__ int wave_max_int(int v) {
     return __builtin_amdgcn_readfirstlane(v);
 }
 
-constexpr int RED_MAXV = 5;    // values reduced together
+constexpr int RED_MAXV = 6;    // values reduced together
 constexpr int RED_MAXW = 16;   // waves per workgroup
 
 // Sum NV per-thread partials over the workgroup; every thread receives the totals.  Wave partials go through LDS and
@@ -104,16 +104,19 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double *red, int &par
         const double t0 = wave_allreduce_sum(v[0]);
         if (lane == 0) buf[w] = t0;
     } else {
-        // values 0..3 share one butterfly (reduce-scatter); a fifth goes alone
+        // values 0..3 share one butterfly (reduce-scatter); a fifth goes alone, a fifth and a sixth share a second one
         constexpr int NS4 = NV > 4 ? 4 : NV;
         const double sc = wave_reduce_scatter<NS4>(v);
 #pragma unroll
         for (int k = 0; k < NS4; k++) if (lane == scatter_lane(NS4, k)) buf[k * RED_MAXW + w] = sc;
-        if constexpr (NV > 4) {
-            static_assert(NV <= 5, "at most five values");
+        if constexpr (NV == 5) {
             const double t4 = wave_allreduce_sum(v[4]);
             if (lane == 0) buf[4 * RED_MAXW + w] = t4;
-        }
+        } else if constexpr (NV == 6) {          // values 4 and 5 share a second butterfly
+            const double sc2 = wave_reduce_scatter<2>(v + 4);
+#pragma unroll
+            for (int k = 0; k < 2; k++) if (lane == scatter_lane(2, k)) buf[(4 + k) * RED_MAXW + w] = sc2;
+        } else static_assert(NV <= 4, "at most six values");
     }
     __syncthreads();
 #ifdef LPBOX_STAGE2_DPP

@@ -50,7 +50,7 @@ struct LdsLayout {
     __host__ __device__ LdsLayout(int NS, int LS, int ZS, bool lean, int HL = 0, int HLD = 0) {
         size_t o = 0;
         auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 15) & ~size_t(15); return at; };
-        gx = take(sizeof(double) * ((size_t)NS + 1));     // + zero slot at [NS]
+        gx = take(sizeof(double) * (2 * (size_t)NS + 3)); // n-vector being gathered + zero slot at [NS]; a second one (the PCG start vector) at [NS + 2 ..], zero slot at [2 NS + 2]
         gl = take(sizeof(double) * 3 * ((size_t)LS + 1)); // three l-vectors interleaved: gl[3*i + c]; zero slot at i = LS
         red = take(sizeof(double) * 2 * RED_MAXV * RED_MAXW);
         hist = take(sizeof(double) * 2 * LP_HIST);        // objective history, double-buffered (read by all, rewritten by thread 0)
@@ -402,7 +402,7 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
         for (int i = tid; i <= bd.NS; i += T) { s_rs_ptr[i] = gp[i]; s_cs_ptr[i] = gc[i]; s_hs_ptr[i] = gh[i]; }
         const uint16_t *c0 = bd.rs_col + oz, *r0 = bd.cs_row + oz;
         for (int k = tid; k < nnz; k += T) { s_rs_col[k] = c0[k]; s_cs_row[k] = r0[k]; }
-        if (tid == 0) { gx[bd.NS] = 0.0; gl[3 * bd.LS] = 0.0; gl[3 * bd.LS + 1] = 0.0; gl[3 * bd.LS + 2] = 0.0; }   // zero slots
+        if (tid == 0) { gx[bd.NS] = 0.0; gx[2 * bd.NS + 2] = 0.0; gl[3 * bd.LS] = 0.0; gl[3 * bd.LS + 1] = 0.0; gl[3 * bd.LS + 2] = 0.0; }   // zero slots
     }
     // ---- direct x-update: the dense inverse H, kept in LDS for the launch (section 17 of DESIGN.md) ----
     double *Hm = (double *)(smem + L.H), *dcol = (double *)(smem + L.dcol), *drow = (double *)(smem + L.drow);
@@ -519,9 +519,10 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
     // out = (E * gx)_row for this thread's row tasks: the G lanes of a task add their interleaved share of the row in
     // ascending column order, then combine by an xor butterfly inside the (aligned) lane group; every lane of the group
     // ends up with the row sum, the leader uses it.
-    auto rows_gather = [&](double (&out)[EPT]) {
+    constexpr int GX2 = T * EPT + 2;             // the second n-vector of gx, as an immediate ds_read offset in doubles
+    auto rows_gather_at = [&](auto COMPC, double (&out)[EPT]) {
         double part[EPT];
-        gather_all<RCAPS, 8, 0>(rl, s_rs_col, op_add, part);
+        gather_all<RCAPS, 8, decltype(COMPC)::value>(rl, s_rs_col, op_add, part);
         static_for<EPT>([&](auto S) {
             constexpr int s = decltype(S)::value;
             double v = part[s];
@@ -531,6 +532,7 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
             out[s] = v;
         });
     };
+    auto rows_gather = [&](double (&out)[EPT]) { rows_gather_at(std::integral_constant<int, 0>{}, out); };
 
     // out = (E^T * gl[.][COMP])_col for this thread's variables through OP.  A long column is shared inside its quad of lanes:
     // its owner adds the leading entries, the other lanes of the quad add consecutive chunks of the rest into a second
@@ -634,37 +636,60 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
         __syncthreads();
         rows_gather(Ex);
 
+        // The first half of an iteration (LPcpp:806-828) needs only what the END of the previous one holds -- x, z1, z2, z4, E x and the
+        // rho of the next iteration: y3 with the published l-vectors, the PCG start vector y1 and this thread's share of the sphere
+        // norm are prepared there, so that the norm rides in the residual reduction and the l-vectors are published by its barrier
+        // (two barriers fewer per iteration than computing them where the reference does; same expressions, same bits).
+        // (one-/two-slot variants carry y1 and the unscaled y2 into the next iteration in registers; the register-lean ones recompute them)
+        double y1c[LEAN ? 1 : EPT], uc[LEAN ? 1 : EPT];
+        auto prepare = [&](double r1, double r2, double r4) {
+            double part = 0.0;
+#pragma unroll
+            for (int s = 0; s < EPT; s++) {
+                const double u = (x[s] + z2.get(s) / r2) - 0.5;       // project_shifted_Lp_ball :423-428
+                part = part + (live[s] ? u * u : 0.0);
+                if constexpr (!DIRECT || !LEAN) {
+                    const double t = x[s] + z1.get(s) / r1;
+                    const double y1n = t > 1 ? 1 : (t < 0 ? 0 : t);   // project_box :409-421
+                    if constexpr (!DIRECT) gx[GX2 + s * T + tid] = live[s] ? y1n : 0.0;      // PCG start x0 = y1 (:892)
+                    if constexpr (!LEAN) { y1c[s] = y1n; uc[s] = u; }
+                }
+                // y3 = max(0, f - E x - z4/rho4), LPcpp:824-828
+                const double fs = f.get(s, rgl(s), rvalid(s)), z4s = z4.get(s, rgl(s), rvalid(s));
+                const double v = fs - Ex[s] - z4s / r4;
+                const double y3s = v < 0 ? 0 : v;
+                y3.set(s, rgl(s), rvalid(s), y3s);
+                if (rvalid(s)) { gl[3 * rgl(s)] = fs - y3s; if constexpr (!LEAN) gl[3 * rgl(s) + 1] = z4s; }
+            }
+            return part;
+        };
+        double pnorm;
+        {
+            double pn[1] = {prepare(rho1, rho2, rho4)};
+            block_sum<T, 1>(pn, red, parity);                         // (its barrier publishes the l-vectors and the start vector)
+            pnorm = pn[0];
+        }
+
         int cc = 0;
         STAMP_DECL
         for (; it < iter_end; ++it) {
             STAMP(15)
             // ---------------- y1 (box) and y2 (shifted L2 sphere), LPcpp:806-818 ----------------
             double y1[EPT], y2[EPT];
-            double pn[1] = {0.0};
+            const double c2 = 2 * sqrt(pnorm);
 #pragma unroll
             for (int s = 0; s < EPT; s++) {
-                const double t = x[s] + z1.get(s) / rho1;
-                y1[s] = t > 1 ? 1 : (t < 0 ? 0 : t);                  // project_box :409-421
-                const double u = (x[s] + z2.get(s) / rho2) - 0.5;     // project_shifted_Lp_ball :423-428
-                y2[s] = u;
-                pn[0] = pn[0] + (live[s] ? u * u : 0.0);
+                if constexpr (LEAN) {
+                    const double t = x[s] + z1.get(s) / rho1;
+                    y1[s] = t > 1 ? 1 : (t < 0 ? 0 : t);
+                    const double u = (x[s] + z2.get(s) / rho2) - 0.5;
+                    y2[s] = u * c1 / c2 + 0.5;
+                } else {
+                    y1[s] = y1c[s];
+                    y2[s] = uc[s] * c1 / c2 + 0.5;
+                }
             }
-            block_sum<T, 1>(pn, red, parity);
-            const double c2 = 2 * sqrt(pn[0]);
-#pragma unroll
-            for (int s = 0; s < EPT; s++) y2[s] = y2[s] * c1 / c2 + 0.5;
             STAMP(0)
-            // ---------------- y3 = max(0, f - E x - z4/rho4), LPcpp:824-828 ----------------
-#pragma unroll
-            for (int s = 0; s < EPT; s++) {
-                const double fs = f.get(s, rgl(s), rvalid(s)), z4s = z4.get(s, rgl(s), rvalid(s));
-                const double v = fs - Ex[s] - z4s / rho4;
-                const double y3s = v < 0 ? 0 : v;
-                y3.set(s, rgl(s), rvalid(s), y3s);
-                if (rvalid(s)) { gl[3 * rgl(s)] = fs - y3s; if constexpr (!LEAN) gl[3 * rgl(s) + 1] = z4s; }
-                gx[s * T + tid] = live[s] ? y1[s] : 0.0;      // PCG start x0 = y1 (:892)
-            }
-            __syncthreads();
             // ---------------- matrix-expression refresh, LPcpp:831-866 ----------------
             if (it == 0) {                                            // update_expression(0)
                 dI = 0.0; dI += rho1 + rho2;
@@ -700,7 +725,7 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
             }
             if constexpr (!DIRECT) {
                 double q[EPT];
-                rows_gather(q);
+                rows_gather_at(std::integral_constant<int, GX2>{}, q);    // q = E y1 (the start vector sits in the second n-vector)
 #pragma unroll
                 for (int s = 0; s < EPT; s++) if (rvalid(s)) gl[3 * rgl(s) + 2] = q[s];
                 __syncthreads();
@@ -955,8 +980,10 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
                 const double d = g4 * ((Ex[s] + y3.get(s, rgl(s), rvalid(s))) - f.get(s, rgl(s), rvalid(s)));
                 z4.set(s, rgl(s), rvalid(s), (!l2f && it == iter_start) ? d : z4.get(s, rgl(s), rvalid(s)) + d);   // :920-923 (plain loop overwrites on its first iteration)
             }
-            // ---------------- residual norms, objective (:931-1011) ----------------
-            double p5[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+            // ---------------- residual norms, objective (:931-1011); the next iteration's first half rides along ----------------
+            const bool rho_step = (it + 1) % LP_RHO_STEP == 0;        // the rho the next iteration will see (:951-970)
+            double p5[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            p5[5] = prepare(rho_step ? learning_fact * rho1 : rho1, rho_step ? learning_fact * rho2 : rho2, rho_step ? learning_fact * rho4 : rho4);
 #pragma unroll
             for (int s = 0; s < EPT; s++) {
                 const double d1 = x[s] - y1[s], d2 = x[s] - y2[s];
@@ -968,7 +995,8 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
                 p5[4] = p5[4] + (live[s] ? b.get(s) * xb : 0.0);
             }
             STAMP(12)
-            block_sum<T, 5>(p5, red, parity);
+            block_sum<T, 6>(p5, red, parity);
+            pnorm = p5[5];
             STAMP(13)
             {
                 const double xn = sqrt(p5[0]);
@@ -981,7 +1009,7 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
                 stop = LP_STOP_Y1Y2;
                 break;
             }
-            if ((it + 1) % LP_RHO_STEP == 0) {                        // :951-970
+            if (rho_step) {                                           // :951-970
                 prev_rho1 = rho1; prev_rho2 = rho2;
                 rho1 = learning_fact * rho1;
                 rho2 = learning_fact * rho2;
@@ -1041,7 +1069,7 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
                 prev_rho1 = uniform_f64(prev_rho1); prev_rho2 = uniform_f64(prev_rho2); prev_rho4 = uniform_f64(prev_rho4);
                 gamma_val = uniform_f64(gamma_val); rcr = uniform_f64(rcr); dI = uniform_f64(dI); r4Et = uniform_f64(r4Et);
                 std_obj = uniform_f64(std_obj); cur_obj = uniform_f64(cur_obj); best_bin_obj = uniform_f64(best_bin_obj);
-                cvg1 = uniform_f64(cvg1); cvg2 = uniform_f64(cvg2); obj_val = uniform_f64(obj_val);
+                cvg1 = uniform_f64(cvg1); cvg2 = uniform_f64(cvg2); obj_val = uniform_f64(obj_val); pnorm = uniform_f64(pnorm);
             }
             STAMP(14)
         }
