@@ -15,7 +15,8 @@ def stats(src, dst, keep=12):
 def counter(path, name, kernel_substr):
     vals = {}
     for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] == name and kernel_substr in r["Kernel_Name"]:
+        # (the default PCG instantiation only: the bench also runs the opt-in direct mode once, template flag "true>")
+        if r["Counter_Name"] == name and kernel_substr in r["Kernel_Name"] and "true>" not in r["Kernel_Name"]:
             vals.setdefault(r["Dispatch_Id"], 0.0)
             vals[r["Dispatch_Id"]] += float(r["Counter_Value"])
     v = list(vals.values())
