@@ -72,7 +72,8 @@ hipError_t seg_launch_init(const SegDev &d, double c1, hipStream_t s);
 hipError_t seg_launch_set_window(const SegDev &d, int iter_start, int iter_end, int l2f, int *parity, hipStream_t s);
 hipError_t seg_launch_fix(const SegDev &d, int n_live_new, double c1_new, int *parity, hipStream_t s);
 // `iters` outer iterations, each = prep, yrhs, resid, kmax x (matvec, update), post  (an even number of launches)
-hipError_t seg_enqueue_iterations(const SegDev &d, int iters, int kmax, int *parity, hipStream_t s);
+hipError_t seg_enqueue_prep(const SegDev &d, int *parity, hipStream_t s);                  // head of a batch of iterations (1 launch)
+hipError_t seg_enqueue_iterations(const SegDev &d, int iters, int kmax, int *parity, hipStream_t s);   // 3 + 2 kmax launches each
 hipError_t seg_enqueue_pcg_more(const SegDev &d, int pairs, int *parity, hipStream_t s);   // resume a stalled PCG, then post
 hipError_t seg_enqueue_finalize(const SegDev &d, int *parity, hipStream_t s);              // finalise the last iteration only
 hipError_t seg_launch_copy(const SegDev &d, int reset_pcg_max, int *parity, hipStream_t s);   // state copy (parity flip), optionally pcg_max = 0

@@ -25,6 +25,7 @@ struct Buf {
     void release() { if (p) (void)hipFree(p); p = nullptr; count = 0; }
 };
 constexpr int ITERS_PER_GRAPH = 4;
+static_assert(ITERS_PER_GRAPH % 2 == 0, "an iteration is an odd number of launches: an even count keeps the ping-pong parity");
 constexpr int SEG_KMAX_LIMIT = 24;
 }  // namespace
 
@@ -215,7 +216,8 @@ int read_state(SegSolver *s) {
     return LPBOX_OK;
 }
 
-// one hipGraph = ITERS_PER_GRAPH outer iterations (an even number of launches, so the state ping-pong parity is preserved)
+// one hipGraph = ITERS_PER_GRAPH (even) outer iterations of 3 + 2 kmax launches: an even number of launches, so the state ping-pong
+// parity is preserved across replays
 int ensure_graph(SegSolver *s) {
     if (s->gexec[s->kmax][s->parity]) return LPBOX_OK;
     int par = s->parity;
@@ -255,8 +257,9 @@ int run_window(SegSolver *s, int iter_end) {
         if (remaining <= 0 && !s->hst.have_prev) break;
         if (s->adaptive && s->hst.outer_total > 0) s->kmax = std::min(SEG_KMAX_LIMIT, std::max(2, s->hst.pcg_max + 2));
         HIPCHK(seg_launch_copy(s->dev(), 1, &s->parity, s->stream));       // pcg_max = 0 for the coming batch
-        s->launches++;
-        const int per_launch = 4 + 2 * s->kmax;
+        HIPCHK(seg_enqueue_prep(s->dev(), &s->parity, s->stream));         // head of the batch (inside it post + yrhs do prep's work)
+        s->launches += 2;
+        const int per_launch = 3 + 2 * s->kmax;
         int batch = std::min(std::max(remaining, 0), 32);
         if (!nograph) { rc = ensure_graph(s); if (rc) return rc; }
         while (!nograph && batch >= ITERS_PER_GRAPH) {

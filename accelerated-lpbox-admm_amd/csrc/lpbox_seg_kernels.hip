@@ -2,7 +2,9 @@
 //
 // n ~ 1e4..1e6, so the vectors live in HBM / L2 and one ADMM iteration is a chain of kernels cut at the algorithm's
 // grid-wide dependencies:
-//   prep    : finalise the previous iteration (stop tests, rho schedule, objective history), partial ||x+z2/rho2-1/2||^2
+//   prep    : (head / tail of a batch of iterations, and every iteration of the multi-problem chain) finalise the previous iteration
+//             (stop tests, rho schedule, objective history), partial ||x+z2/rho2-1/2||^2; inside a single-problem batch `post` and
+//             `yrhs` do this work and the launch is dropped
 //   yrhs    : y1, y2, diagonal/preconditioner refresh, rhs, PCG start x0 = y1
 //   resid   : r = rhs - (2A+(rho1+rho2)I) x0,  p = r/diag, partials rhs.rhs, r.r, r.p
 //   matvec  : [beta, p = z + beta p]  tmp = M p, partial p.tmp          \  one PCG iteration = 2 launches: the p update of
@@ -161,7 +163,71 @@ __global__ void __launch_bounds__(T) seg_k_fix(SegDev d, int in, int out, int n_
     }
 }
 
-// prep: finalise the previous iteration (workgroup 0 only), then start the next one
+// ---- finalisation of an iteration (SEGcpp:1122-1180 / :1277-1376): the totals of what `post` left as workgroup partials ...
+__device__ __forceinline__ void finalise_sums(const SegDev &d, double (&e)[5], double (&e2)[2], double *red, int &parity) {
+    final_sums<5>(d, PH_E, e, red, parity);                                  // x.x, |x-y1|^2, |x-y2|^2, x.Ax, b.x
+    const double *p5 = part_ptr(d, PH_E, 5), *p6 = part_ptr(d, PH_E, 6);
+    double a = 0.0, b2 = 0.0;
+    for (int q = threadIdx.x; q < d.G; q += T) { a = a + p5[q]; b2 = b2 + p6[q]; }
+    e2[0] = a; e2[1] = b2;
+    block_sum<T, 2>(e2, red, parity);                                        // xb.A xb, b.xb
+}
+// ... and the scalar decisions on them, applied to a copy *s of the state (one thread): stop tests, rho schedule, objective history
+__device__ __forceinline__ void finalise_state(SegState *s, const double (&e)[5], const double (&e2)[2]) {
+    const int it = s->iter;
+    s->have_prev = 0;
+    const double xn = sqrt(e[0]);
+    const double t0 = xn < 2.2204e-16 ? 2.2204e-16 : xn;
+    s->cvg1 = sqrt(e[1]) / t0; s->cvg2 = sqrt(e[2]) / t0;
+    const double bin_cost = e2[0] + e2[1];                       // compute_cost(round(x)) (:1167 / :1372)
+    bool stopped = false;
+    if (s->cvg1 <= SEG_STOP_THRESHOLD && s->cvg2 <= SEG_STOP_THRESHOLD) {   // :1127 / :1282
+        if (s->l2f) s->ret = 1;
+        s->stop = SEG_STOP_XYY; stopped = true;
+    } else {
+        if ((it + 1) % SEG_RHO_STEP == 0) {                      // :1137-1145
+            s->prev_rho1 = s->rho1; s->prev_rho2 = s->rho2;
+            s->rho1 = SEG_LEARNING_FACT * s->rho1; s->rho2 = SEG_LEARNING_FACT * s->rho2;
+            const double g = s->gamma_val * SEG_GAMMA_FACTOR;
+            s->gamma_val = g < 1.0 ? 1.0 : g;
+            s->rhoUpdated = 1; s->rcr = SEG_LEARNING_FACT - 1.0;
+        }
+        s->obj_val = e[3] + e[4];                                // compute_cost(x) (:1148)
+        int hn = s->hist_n;
+        if (hn < SEG_HIST) s->hist[hn] = s->obj_val;
+        else { for (int k = 0; k < SEG_HIST - 1; k++) s->hist[k] = s->hist[k + 1]; s->hist[SEG_HIST - 1] = s->obj_val; }
+        if (hn < 0x3fffffff) hn++;
+        s->hist_n = hn;
+        if (hn >= SEG_HIST) {
+            double mean = 0;
+            for (int k = 0; k < SEG_HIST; k++) mean += s->hist[k];
+            mean /= (double)SEG_HIST;
+            double dev = 0;
+            for (int k = 0; k < SEG_HIST; k++) dev += (s->hist[k] - mean) * (s->hist[k] - mean);
+            dev /= (double)(SEG_HIST - 1);
+            const double sd = dev == 0 ? 0.0 : sqrt(dev);
+            s->std_obj = sd / fabs(s->hist[SEG_HIST - 1]);
+        }
+        if (s->std_obj <= SEG_STD_THRESHOLD) { if (s->l2f) s->ret = 1; s->stop = SEG_STOP_OBJSTD; stopped = true; }
+        else {
+            s->cur_obj = bin_cost;
+            if (s->best_bin_obj >= s->cur_obj) s->best_bin_obj = s->cur_obj;
+        }
+    }
+    if (stopped) {
+        s->halt = SEG_HALT_STOP;
+        if (!s->l2f) { s->cur_obj = bin_cost; s->legacy_iter_p1 = it + 1; }   // legacy epilogue (:1371-1376)
+    } else s->iter = it + 1;
+}
+// the window ends here / another iteration follows
+__device__ __forceinline__ void close_or_continue(SegState *s, int do_prep) {
+    if (!s->halt && s->iter >= s->iter_end) { s->halt = SEG_HALT_WINDOW; if (!s->l2f) s->legacy_iter_p1 = s->iter + 1; }
+    if (!s->halt && do_prep) s->phase = 1;
+}
+
+// prep: finalise the previous iteration if that is still pending (workgroup 0 only), then the sphere-norm partials of the next one.
+// Launched at the head of a batch of iterations and (do_prep = 0) at its end; INSIDE a batch `post` leaves those partials and `yrhs`
+// finalises (every workgroup for itself), so an iteration is 3 + 2 kmax launches.
 __device__ __forceinline__ void seg_b_prep(const SegDev &d, int in, int out, int do_prep) {
     __shared__ double red[2 * RED_MAXV * RED_MAXW];
     int parity = 0;
@@ -175,64 +241,12 @@ __device__ __forceinline__ void seg_b_prep(const SegDev &d, int in, int out, int
     const bool will_prep = do_prep && !halt0 && next_iter < iter_end;       // (a stop detected below only wastes this launch's partials)
     if (blockIdx.x == 0) {
         double e[5] = {0, 0, 0, 0, 0}, e2[2] = {0, 0};
-        if (fin) {                                                          // uniform over the workgroup
-            final_sums<5>(d, PH_E, e, red, parity);                          // x.x, |x-y1|^2, |x-y2|^2, x.Ax, b.x
-            const double *p5 = part_ptr(d, PH_E, 5), *p6 = part_ptr(d, PH_E, 6);
-            double a = 0.0, b2 = 0.0;
-            for (int q = threadIdx.x; q < d.G; q += T) { a = a + p5[q]; b2 = b2 + p6[q]; }
-            e2[0] = a; e2[1] = b2;
-            block_sum<T, 2>(e2, red, parity);                                // xb.A xb, b.xb
-        }
+        if (fin) finalise_sums(d, e, e2, red, parity);                       // uniform over the workgroup
         if (threadIdx.x == 0) {
             d.st[out] = *si;
             SegState *s = d.st + out;
-            if (fin) {
-                s->have_prev = 0;
-                const double xn = sqrt(e[0]);
-                const double t0 = xn < 2.2204e-16 ? 2.2204e-16 : xn;
-                s->cvg1 = sqrt(e[1]) / t0; s->cvg2 = sqrt(e[2]) / t0;
-                const double bin_cost = e2[0] + e2[1];                       // compute_cost(round(x)) (:1167 / :1372)
-                bool stopped = false;
-                if (s->cvg1 <= SEG_STOP_THRESHOLD && s->cvg2 <= SEG_STOP_THRESHOLD) {   // :1127 / :1282
-                    if (s->l2f) s->ret = 1;
-                    s->stop = SEG_STOP_XYY; stopped = true;
-                } else {
-                    if ((it + 1) % SEG_RHO_STEP == 0) {                      // :1137-1145
-                        s->prev_rho1 = s->rho1; s->prev_rho2 = s->rho2;
-                        s->rho1 = SEG_LEARNING_FACT * s->rho1; s->rho2 = SEG_LEARNING_FACT * s->rho2;
-                        const double g = s->gamma_val * SEG_GAMMA_FACTOR;
-                        s->gamma_val = g < 1.0 ? 1.0 : g;
-                        s->rhoUpdated = 1; s->rcr = SEG_LEARNING_FACT - 1.0;
-                    }
-                    s->obj_val = e[3] + e[4];                                // compute_cost(x) (:1148)
-                    int hn = s->hist_n;
-                    if (hn < SEG_HIST) s->hist[hn] = s->obj_val;
-                    else { for (int k = 0; k < SEG_HIST - 1; k++) s->hist[k] = s->hist[k + 1]; s->hist[SEG_HIST - 1] = s->obj_val; }
-                    if (hn < 0x3fffffff) hn++;
-                    s->hist_n = hn;
-                    if (hn >= SEG_HIST) {
-                        double mean = 0;
-                        for (int k = 0; k < SEG_HIST; k++) mean += s->hist[k];
-                        mean /= (double)SEG_HIST;
-                        double dev = 0;
-                        for (int k = 0; k < SEG_HIST; k++) dev += (s->hist[k] - mean) * (s->hist[k] - mean);
-                        dev /= (double)(SEG_HIST - 1);
-                        const double sd = dev == 0 ? 0.0 : sqrt(dev);
-                        s->std_obj = sd / fabs(s->hist[SEG_HIST - 1]);
-                    }
-                    if (s->std_obj <= SEG_STD_THRESHOLD) { if (s->l2f) s->ret = 1; s->stop = SEG_STOP_OBJSTD; stopped = true; }
-                    else {
-                        s->cur_obj = bin_cost;
-                        if (s->best_bin_obj >= s->cur_obj) s->best_bin_obj = s->cur_obj;
-                    }
-                }
-                if (stopped) {
-                    s->halt = SEG_HALT_STOP;
-                    if (!s->l2f) { s->cur_obj = bin_cost; s->legacy_iter_p1 = it + 1; }   // legacy epilogue (:1371-1376)
-                } else s->iter = it + 1;
-            }
-            if (!s->halt && s->iter >= s->iter_end) { s->halt = SEG_HALT_WINDOW; if (!s->l2f) s->legacy_iter_p1 = s->iter + 1; }
-            if (!s->halt && do_prep) s->phase = 1;
+            if (fin) finalise_state(s, e, e2);
+            close_or_continue(s, do_prep);
         }
     }
     if (!will_prep) return;
@@ -251,6 +265,17 @@ __device__ __forceinline__ void seg_b_yrhs(const SegDev &d, int in, int out) {
     int parity = 0;
     const SegState *si = d.st + in;
     if (si->halt) { forward_state(d, in, out); return; }
+    // inside a batch the previous iteration is still to be finalised (its `post` left the partials): every workgroup does that for
+    // itself -- same sums, same scalar code, same result -- on a copy of the state in LDS; workgroup 0 publishes it
+    __shared__ SegState fst;
+    if (si->have_prev) {                                                     // uniform over the grid
+        double e[5] = {0, 0, 0, 0, 0}, e2[2] = {0, 0};
+        finalise_sums(d, e, e2, red, parity);
+        if (threadIdx.x == 0) { fst = *si; finalise_state(&fst, e, e2); close_or_continue(&fst, 1); }
+        __syncthreads();
+        si = &fst;
+        if (si->halt) { if (LEADER) d.st[out] = fst; return; }
+    }
     const double rho1 = si->rho1, rho2 = si->rho2, c1 = si->c1;
     const int rhoUpdated = si->rhoUpdated, stale = si->dinv_stale;
     const bool refresh = si->iter != 0 && rhoUpdated;
@@ -409,16 +434,20 @@ __device__ __forceinline__ void seg_b_post(const SegDev &d, int in, int out) {
         else { if (LEADER) { d.st[out] = *si; d.st[out].halt = SEG_HALT_PCG_MORE; } return; }
     }
     const double g1 = si->gamma_val * si->rho1, g2 = si->gamma_val * si->rho2;
+    // the rho2 of the NEXT iteration (rho schedule :1137-1145; if this iteration turns out to stop, the partial below is simply not used)
+    const double rho2n = (si->iter + 1) % SEG_RHO_STEP == 0 ? SEG_LEARNING_FACT * si->rho2 : si->rho2;
     const double *x = d.x;
-    double e5[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, e2[2] = {0.0, 0.0};
+    double e5[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, e2[3] = {0.0, 0.0, 0.0};
     double *xh = (rec && cc < d.ws_cap) ? d.xhist + (size_t)cc * d.n : nullptr;
     for (int q = 0; q < d.EPT; q++) {
         const int i = blockIdx.x * (T * d.EPT) + q * T + threadIdx.x;
-        double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0, v4 = 0.0, v5 = 0.0, v6 = 0.0;
+        double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0, v4 = 0.0, v5 = 0.0, v6 = 0.0, v7 = 0.0;
         if (i < d.n && d.live[i]) {
             const double xi = x[i], y1 = d.y1[i], y2 = d.y2[i], bi = d.b[i];
             d.z1[i] = d.z1[i] + g1 * (xi - y1);                               // :1119-1120
-            d.z2[i] = d.z2[i] + g2 * (xi - y2);
+            const double z2n = d.z2[i] + g2 * (xi - y2);
+            d.z2[i] = z2n;
+            { const double u = (xi + z2n / rho2n) - 0.5; v7 = u * u; }           // next iteration's ||x + z2/rho2 - 1/2||^2 (:1075-1080)
             if (xh) xh[i] = xi;                                               // x_iters column (:1113-1116)
             // A x and A round(x) in one pass over the row (compute_cost :568-572, A_ptr restricted to the live variables)
             double t1 = 0, t2 = 0;
@@ -448,14 +477,15 @@ __device__ __forceinline__ void seg_b_post(const SegDev &d, int in, int out) {
             v0 = xi * xi; v1 = d1 * d1; v2 = d2 * d2; v3 = xi * Ax; v4 = bi * xi; v5 = xb * Axb; v6 = bi * xb;
         }
         e5[0] = e5[0] + v0; e5[1] = e5[1] + v1; e5[2] = e5[2] + v2; e5[3] = e5[3] + v3; e5[4] = e5[4] + v4;
-        e2[0] = e2[0] + v5; e2[1] = e2[1] + v6;
+        e2[0] = e2[0] + v5; e2[1] = e2[1] + v6; e2[2] = e2[2] + v7;
     }
     block_sum<T, 5>(e5, red, parity);
-    block_sum<T, 2>(e2, red, parity);
+    block_sum<T, 3>(e2, red, parity);
     if (threadIdx.x == 0) {
         for (int k = 0; k < 5; k++) part_ptr(d, PH_E, k)[blockIdx.x] = e5[k];
         part_ptr(d, PH_E, 5)[blockIdx.x] = e2[0];
         part_ptr(d, PH_E, 6)[blockIdx.x] = e2[1];
+        part_ptr(d, PH_A, 0)[blockIdx.x] = e2[2];
     }
     if (LEADER) {
         d.st[out] = *si;
@@ -525,9 +555,13 @@ hipError_t seg_launch_fix(const SegDev &d, int n_live_new, double c1_new, int *p
     return hipGetLastError();
 }
 
+hipError_t seg_enqueue_prep(const SegDev &d, int *parity, hipStream_t s) {      // head of a batch of iterations
+    SEG_LAUNCH(seg_k_prep, d.G, 1);
+    return hipGetLastError();
+}
+
 hipError_t seg_enqueue_iterations(const SegDev &d, int iters, int kmax, int *parity, hipStream_t s) {
     for (int it = 0; it < iters; it++) {
-        SEG_LAUNCH(seg_k_prep, d.G, 1);
         SEG_LAUNCH(seg_k_yrhs, d.G);
         SEG_LAUNCH(seg_k_resid, d.G);
         for (int k = 0; k < kmax; k++) { SEG_LAUNCH(seg_k_matvec, d.G); SEG_LAUNCH(seg_k_update, d.G); }
@@ -582,6 +616,8 @@ hipError_t segb_launch_copy(const SegDev *devs, int B, int reset_pcg_max, int *p
     return hipGetLastError();
 }
 hipError_t segb_enqueue_iterations(const SegDev *devs, int B, int Gmax, int iters, int kmax, int *parity, hipStream_t s) {
+    // (a batch keeps the prep launch per iteration: with B x G workgroups the redundant finalisation inside yrhs costs more than the
+    //  launch it saves -- 150 vs 137 ms for 100 images at 10^4 nodes; the single-problem chain drops it)
     for (int it = 0; it < iters; it++) {
         SEG_LAUNCH_B(seg_kb_prep, Gmax, 1);
         SEG_LAUNCH_B(seg_kb_yrhs, Gmax);
