@@ -242,6 +242,12 @@ void drop_graphs(SegSolver *s) {
 // pairs halts itself (SEG_HALT_PCG_MORE) and is resumed here.
 int run_window(SegSolver *s, int iter_end) {
     static const bool nograph = getenv("LPBOX_SEG_NOGRAPH") != nullptr;   // eager launches (profilers that dislike graphs)
+    // spare (matvec, update) pairs per iteration beyond the largest PCG count of the previous batch of <= 32 iterations.  A spare pair
+    // is a launch that falls through (~3 us); a PCG that needs more than was enqueued halts the chain and is resumed (a host round
+    // trip).  Measured over 100 images at 10^4 nodes and the full-resolution one: 0 spare pairs 8 % / 7 % faster than 2, 1 in between
+    // -- the counts drift slowly, misses are rare.  LPBOX_SEG_KMARGIN overrides (also for the multi-problem chain, which defaults to 2:
+    // there one late problem stalls all).
+    static const int kmargin = getenv("LPBOX_SEG_KMARGIN") ? std::max(0, atoi(getenv("LPBOX_SEG_KMARGIN"))) : 0;
     HIPCHK(hipEventRecord(s->ev0, s->stream));
     for (;;) {
         int rc = read_state(s);
@@ -255,7 +261,7 @@ int run_window(SegSolver *s, int iter_end) {
         if (s->hst.halt != SEG_HALT_NONE) break;
         const int remaining = iter_end - s->hst.iter;
         if (remaining <= 0 && !s->hst.have_prev) break;
-        if (s->adaptive && s->hst.outer_total > 0) s->kmax = std::min(SEG_KMAX_LIMIT, std::max(2, s->hst.pcg_max + 2));
+        if (s->adaptive && s->hst.outer_total > 0) s->kmax = std::min(SEG_KMAX_LIMIT, std::max(2, s->hst.pcg_max + kmargin));
         HIPCHK(seg_launch_copy(s->dev(), 1, &s->parity, s->stream));       // pcg_max = 0 for the coming batch
         HIPCHK(seg_enqueue_prep(s->dev(), &s->parity, s->stream));         // head of the batch (inside it post + yrhs do prep's work)
         s->launches += 2;
@@ -411,6 +417,7 @@ int segc_legacy_batch(SegSolver **ss, int B, int *energies) {
         HIPCHK(hipStreamSynchronize(st));
         return LPBOX_OK;
     };
+    static const int bmargin = getenv("LPBOX_SEG_KMARGIN") ? std::max(0, atoi(getenv("LPBOX_SEG_KMARGIN"))) : 2;
     HIPCHK(hipEventRecord(s0->ev0, st));
     HIPCHK(segb_launch_init(devs.p, B, Gmax, st));
     HIPCHK(segb_launch_set_window(devs.p, B, 0, SEG_MAX_ITERS, 0, &parity, st));
@@ -426,7 +433,7 @@ int segc_legacy_batch(SegSolver **ss, int B, int *energies) {
             if (h.halt != SEG_HALT_NONE) continue;
             const int rem = SEG_MAX_ITERS - h.iter;
             if (rem <= 0 && !h.have_prev) continue;
-            any_run = true; remaining = std::max(remaining, rem); pcg_max = std::max(pcg_max, h.outer_total > 0 ? h.pcg_max : kmax - 2);
+            any_run = true; remaining = std::max(remaining, rem); pcg_max = std::max(pcg_max, h.outer_total > 0 ? h.pcg_max : kmax - bmargin);
         }
         if (more) {                                                 // some PCG ran out of launches: resume it (the others fall through)
             HIPCHK(segb_enqueue_pcg_more(devs.p, B, Gmax, 16, &parity, st));
@@ -435,7 +442,7 @@ int segc_legacy_batch(SegSolver **ss, int B, int *energies) {
             continue;
         }
         if (!any_run) break;
-        if (s0->adaptive) kmax = std::min(SEG_KMAX_LIMIT, std::max(2, pcg_max + 2));
+        if (s0->adaptive) kmax = std::min(SEG_KMAX_LIMIT, std::max(2, pcg_max + bmargin));
         HIPCHK(segb_launch_copy(devs.p, B, 1, &parity, st));
         const int batch = std::min(std::max(remaining, 0), 32);
         if (batch > 0) HIPCHK(segb_enqueue_iterations(devs.p, B, Gmax, batch, kmax, &parity, st));
