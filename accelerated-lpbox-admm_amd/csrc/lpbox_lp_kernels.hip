@@ -1131,7 +1131,7 @@ size_t lp_window_lds_bytes(int T, int NS, int LS, int ZS, int HL, int HLD) {
     return LdsLayout(NS, LS, ZS, NS / T >= 4, HL, HLD).total;
 }
 
-bool lp_direct_supported(int T, int EPT) { return (T == 512 || T == 256) && EPT == 1; }
+bool lp_direct_supported(int T, int EPT) { return T == 512 && EPT == 1; }     // the default geometry of every n <= 512 batch
 
 // (threads, slots per thread) -> per-slot register capacities of the row-task / column gather lists.
 #define LP_DISPATCH(KERNEL_CALL)                                                                                                          \
@@ -1166,7 +1166,7 @@ hipError_t lp_launch_window(const LpBatchDev &bd, int T, int EPT, size_t lds, in
         if (e != hipSuccess) return e;                                                                         \
         hipLaunchKernelGGL(kfn, dim3(bd.B), dim3(TT), lds, s, bd, iter_start, iter_end, l2f);                  \
     }
-        if (T == 512) CALL_DIRECT(512) else CALL_DIRECT(256)
+        CALL_DIRECT(512)
 #undef CALL_DIRECT
         return hipGetLastError();
     }
