@@ -4,7 +4,10 @@ the HIP solver (its own summation order) and by the CPU oracle in Eigen's order 
 restated).  Writes gpurun_out/objective_study_<name>.npz: per instance objective (maximisation sign),
 outer iterations, stop reason, infeasible rows -- the data behind tests/test_objective_gap.py and north_star's "objective gap <= reference".
 
-usage: python tools/objective_study.py [fixture.npz] [count] [workers]
+With a trailing "direct" both sides use the opt-in direct x-update (the oracle in Eigen's order with the row
+split the library chose) -> gpurun_out/objective_study_direct_<name>.npz, the data behind tests/test_objective_gap.py's direct-mode tests.
+
+usage: python tools/objective_study.py [fixture.npz] [count] [workers] [direct]
 """
 import os
 import sys
@@ -19,9 +22,10 @@ import numpy as np  # noqa: E402
 from bench import load_instances  # noqa: E402
 
 
-def eigen_solve(I):
+def eigen_solve(job):
     from oracle import oracle as O
-    s = O.LpOracle(0, order=O.ORDER_EIGEN)
+    I, rows = job
+    s = O.LpOracle(0, order=O.ORDER_EIGEN, x_update="direct" if rows is not None else "pcg", direct_rows=rows)
     s.set_problem(I["n"], I["l"], I["colptr"], I["rowidx"], I["b"])
     s.solve_init()
     s.solve_iter(0, 20000)
@@ -29,15 +33,19 @@ def eigen_solve(I):
 
 
 def main():
-    fixture = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tests", "golden", "lp_100_500_seed0.npz")
+    direct = sys.argv[-1] == "direct"
+    argv = sys.argv[:-1] if direct else sys.argv
+    fixture = argv[1] if len(argv) > 1 else os.path.join(ROOT, "tests", "golden", "lp_100_500_seed0.npz")
     insts = load_instances(fixture)
-    count = int(sys.argv[2]) if len(sys.argv) > 2 else len(insts)
-    workers = int(sys.argv[3]) if len(sys.argv) > 3 else min(16, os.cpu_count() or 1)
+    count = int(argv[2]) if len(argv) > 2 else len(insts)
+    workers = int(argv[3]) if len(argv) > 3 else min(16, os.cpu_count() or 1)
     insts = insts[:count]
     from lpbox_hip.lp import LpBatch
     from oracle import oracle as O
     O.build()
     b = LpBatch(insts)
+    if direct:
+        b.set_x_update("direct")
     b.solve_init()
     t0 = time.perf_counter()
     b.solve_iter(0, 20000)
@@ -49,11 +57,11 @@ def main():
     g_inf = np.array([b.check_infeasible_l2f(i) for i in range(count)])
     t0 = time.perf_counter()
     with ProcessPoolExecutor(workers) as ex:
-        res = list(ex.map(eigen_solve, insts, chunksize=2))
+        res = list(ex.map(eigen_solve, [(I, b.direct_rows(i) if direct else None) for i, I in enumerate(insts)], chunksize=2))
     t_cpu = time.perf_counter() - t0
     e_obj, e_it, e_stop, e_inf, e_pcg = (np.array(v) for v in zip(*res))
     name = os.path.splitext(os.path.basename(fixture))[0]
-    out = os.path.join(ROOT, "gpurun_out", "objective_study_%s.npz" % name)
+    out = os.path.join(ROOT, "gpurun_out", "objective_study_%s%s.npz" % ("direct_" if direct else "", name))
     os.makedirs(os.path.dirname(out), exist_ok=True)
     np.savez_compressed(out, gpu_obj=g_obj, gpu_iters=g_it, gpu_pcg=g_pcg, gpu_stop=g_stop, gpu_infeasible=g_inf,
                         eigen_obj=e_obj, eigen_iters=e_it, eigen_pcg=e_pcg, eigen_stop=e_stop, eigen_infeasible=e_inf,
