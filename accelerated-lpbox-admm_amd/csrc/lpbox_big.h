@@ -36,8 +36,10 @@ struct BigState {
 
 struct BigDev {
     int n_loc, l, G, Gl, EPT, EPTl;       // G workgroups over the local variables, Gl over the rows
+    int P, Glr;                           // column slices of the row-side storage (1 = plain CSR); workgroups of big_k_rows at one row per thread
     long n_glob;
-    // E restricted to the local columns: CSR (rows -> local column index) and CSC (local column -> rows), values all 1
+    // E restricted to the local columns: CSR (rows -> local column index; slice-major when P > 1: rptr has P * l + 1 entries, see
+    // row_sum_sliced) and CSC (local column -> rows), values all 1
     const int *rptr, *rcol, *cptr, *crow;
     double *x, *y1, *y2, *z1, *z2, *b, *pd, *dinv, *rhs, *r, *z, *tmp, *p0, *p1, *gsrc;   // local n-vectors
     double *y3, *z4, *f, *fy, *Ex, *q;    // replicated l-vectors (q doubles as the all-reduce buffer of E*v)

@@ -80,7 +80,7 @@ struct lpbox_big {
     std::map<std::pair<int, int>, hipGraphExec_t> gexec; std::vector<hipGraph_t> graphs;
     long long graph_launches = 0, graph_collectives = 0;       // of ONE replay (measured while capturing)
     bool use_graph = true;
-    int G = 0, Gl = 0, EPT = 2, EPTl = 2, kmax = 28, parity = 0;
+    int G = 0, Gl = 0, EPT = 2, EPTl = 2, P = 1, Glr = 0, kmax = 28, parity = 0;
     bool adaptive = true;
     double kernel_ms = 0.0; long long launches = 0, collectives = 0;
     Buf<int> d_rptr, d_rcol, d_cptr, d_crow;
@@ -97,7 +97,7 @@ struct lpbox_big {
 
     BigDev dev() const {
         BigDev d;
-        d.n_loc = n_loc; d.l = l; d.G = G; d.Gl = Gl; d.EPT = EPT; d.EPTl = EPTl; d.n_glob = n_glob;
+        d.n_loc = n_loc; d.l = l; d.G = G; d.Gl = Gl; d.EPT = EPT; d.EPTl = EPTl; d.P = P; d.Glr = Glr; d.n_glob = n_glob;
         d.rptr = d_rptr.p; d.rcol = d_rcol.p; d.cptr = d_cptr.p; d.crow = d_crow.p;
         d.x = x.p; d.y1 = y1.p; d.y2 = y2.p; d.z1 = z1.p; d.z2 = z2.p; d.b = db.p; d.pd = pd.p; d.dinv = dinv.p; d.rhs = rhs.p;
         d.r = r.p; d.z = z.p; d.tmp = tmp.p; d.p0 = p0.p; d.p1 = p1.p; d.gsrc = gsrc.p;
@@ -322,12 +322,28 @@ int lpbox_big_set_problem(lpbox_big_t *h, long n_glob, int c0, int n_loc, int l,
     }
     h->n_glob = n_glob; h->c0 = c0; h->n_loc = n_loc; h->l = l; h->nnz = nnz;
     h->cptr.assign(colptr, colptr + n_loc + 1); h->crow.assign(rowidx, rowidx + nnz);
-    h->rptr.assign((size_t)l + 1, 0);
-    for (int k = 0; k < nnz; k++) h->rptr[rowidx[k] + 1]++;
-    for (int i = 0; i < l; i++) h->rptr[i + 1] += h->rptr[i];
+    // Row-side storage, slice-major (lpbox_big_kernels.hip row_sum_sliced): the columns are cut into P slices of SW columns so that
+    // one slice of the gathered (z, p) table (16 B per variable) stays resident in an XCD's L2; run (slice ph, row i) starts at
+    // rptr[ph * l + i] and the runs follow each other.  P = 1 (a shard that fits anyway, or LPBOX_BIG_SLICE_KB=0) is plain CSR.
+    long slice_kb = 2048;
+    if (const char *e = getenv("LPBOX_BIG_SLICE_KB")) slice_kb = atol(e);
+    long SW = slice_kb > 0 ? std::max<long>(1024, slice_kb * 1024 / 16) : (long)n_loc;
+    int P = (int)std::min<long>(((long)n_loc + SW - 1) / SW, 64);
+    if (P <= 1) { P = 1; SW = n_loc; } else SW = ((long)n_loc + P - 1) / P;
+    if ((size_t)P * (size_t)l + 1 > (size_t)INT32_MAX) { P = 1; SW = n_loc; }
+    h->P = P;
+    h->rptr.assign((size_t)P * l + 1, 0);
+    for (int j = 0; j < n_loc; j++) {
+        const size_t base = (size_t)(j / SW) * l + 1;
+        for (int k = colptr[j]; k < colptr[j + 1]; k++) h->rptr[base + rowidx[k]]++;
+    }
+    for (size_t i = 0; i < (size_t)P * l; i++) h->rptr[i + 1] += h->rptr[i];
     h->rcol.assign(nnz, 0);
     std::vector<int> cur(h->rptr.begin(), h->rptr.end() - 1);
-    for (int j = 0; j < n_loc; j++) for (int k = colptr[j]; k < colptr[j + 1]; k++) h->rcol[cur[rowidx[k]]++] = j;
+    for (int j = 0; j < n_loc; j++) {
+        const size_t base = (size_t)(j / SW) * l;
+        for (int k = colptr[j]; k < colptr[j + 1]; k++) h->rcol[cur[base + rowidx[k]]++] = j;
+    }
     h->b.assign(b, b + n_loc);
     if (f) h->f.assign(f, f + l); else h->f.assign(l, 1.0);
     h->has_problem = true;
@@ -343,9 +359,10 @@ int lpbox_big_init(lpbox_big_t *h) {
         h->EPT = 2; while ((n + BIG_T * h->EPT - 1) / (BIG_T * h->EPT) > 2 * BIG_T * 8 && h->EPT < 64) h->EPT *= 2;
         h->G = (n + BIG_T * h->EPT - 1) / (BIG_T * h->EPT);
         h->EPTl = 2; h->Gl = (l + BIG_T * h->EPTl - 1) / (BIG_T * h->EPTl);
+        h->Glr = (l + BIG_T - 1) / BIG_T;
         if (!h->stream) { HIPCHK(hipStreamCreate(&h->stream)); h->own_stream = true; }
         HIPCHK(hipEventCreate(&h->ev0)); HIPCHK(hipEventCreate(&h->ev1));
-        HIPCHK(h->d_rptr.alloc((size_t)l + 1)); HIPCHK(h->d_rcol.alloc(h->nnz)); HIPCHK(h->d_cptr.alloc((size_t)n + 1)); HIPCHK(h->d_crow.alloc(h->nnz));
+        HIPCHK(h->d_rptr.alloc((size_t)h->P * l + 1)); HIPCHK(h->d_rcol.alloc(h->nnz)); HIPCHK(h->d_cptr.alloc((size_t)n + 1)); HIPCHK(h->d_crow.alloc(h->nnz));
         for (Buf<double> *bp : {&h->x, &h->y1, &h->y2, &h->z1, &h->z2, &h->db, &h->pd, &h->dinv, &h->rhs, &h->r, &h->z, &h->tmp, &h->p0, &h->p1, &h->gsrc, &h->xt})
             HIPCHK(bp->alloc(n));
         HIPCHK(h->live.alloc(n)); HIPCHK(h->newfix.alloc(n)); HIPCHK(h->d_live_idx.alloc(n)); HIPCHK(h->zp.alloc(n));
@@ -357,7 +374,7 @@ int lpbox_big_init(lpbox_big_t *h) {
         else if (h->ag) HIPCHK(h->gath.alloc((size_t)h->world * (size_t)std::max(l, 64)));              // W whole contributions
         HIPCHK(h->flag.alloc(8));
         HIPCHK(h->part.alloc((size_t)BIG_NPART * h->G)); HIPCHK(h->red.alloc(BIG_NPART)); HIPCHK(h->st.alloc(2));
-        HIPCHK(hipMemcpy(h->d_rptr.p, h->rptr.data(), sizeof(int) * ((size_t)l + 1), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_rptr.p, h->rptr.data(), sizeof(int) * ((size_t)h->P * l + 1), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d_rcol.p, h->rcol.data(), sizeof(int) * (size_t)h->nnz, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d_cptr.p, h->cptr.data(), sizeof(int) * ((size_t)n + 1), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d_crow.p, h->crow.data(), sizeof(int) * (size_t)h->nnz, hipMemcpyHostToDevice));
@@ -573,7 +590,7 @@ int lpbox_big_get_scalar(lpbox_big_t *h, const char *name, double *out) {
         {"sum_fix_obj", s.sum_fix_obj}, {"fix_obj", s.fix_obj}, {"c1", s.c1}, {"ret", (double)s.ret}, {"n_live", (double)h->n_live_glob},
         {"stop", (double)s.stop}, {"plain_iter_p1", (double)s.plain_iter_p1}, {"kmax", (double)h->kmax},
         {"launches", (double)h->launches}, {"collectives", (double)h->collectives}, {"kernel_ms", h->kernel_ms},
-        {"threads", (double)BIG_T}, {"chunk", (double)(BIG_T * h->EPT)}, {"groups", (double)h->G},
+        {"threads", (double)BIG_T}, {"chunk", (double)(BIG_T * h->EPT)}, {"groups", (double)h->G}, {"row_slices", (double)h->P},
     };
     for (auto &e : tab) if (!strcmp(e.n, name)) { *out = e.v; return LPBOX_OK; }
     return lpbox_fail(LPBOX_E_BADARG, "unknown scalar '%s'", name);

@@ -235,6 +235,60 @@ __global__ void __launch_bounds__(T) big_k_rhs_cols(BigDev d, int in, int out) {
 
 // q_part = E[:, shard] * v over this rank's columns.  mode 0: v = gsrc.  mode 1: v = the PCG search direction, with the exit
 // test / beta of the previous PCG iteration evaluated here (LPcpp:296-319).
+// Row i of E[:, shard] * v when the table being gathered does not fit an XCD's L2 (n_loc * 16 B > the slice size, i.e. the
+// single-GPU run of a 1e6-variable LP): the entries are stored SLICE-major -- slice ph holds the columns [ph * SW, (ph + 1) * SW),
+// and inside a slice the rows follow each other, each with its entries in ascending column order (d.rptr[ph * l + i] is the start
+// of the run of (slice ph, row i); the runs are consecutive, so the next pointer is its end).  Every thread walks the slices in
+// order, which is still the ascending column order of its row: the sum is bit for bit the one of the unsliced loop.  What
+// changes is WHEN a column is touched: all workgroups of the launch are co-resident and progress at the same pace, so at any
+// time the whole chip gathers from ONE slice of (z, p) -- 1-2 MB, resident in every XCD's 4 MB L2 -- instead of drawing random
+// 128-byte lines of a 16 MB table from the Infinity Cache at 12 % utilisation.  Runs are short (~1.5 entries), so the loop is
+// software-pipelined over the slices: pointers two slices ahead, indices one slice ahead, gathers of the current slice.
+constexpr int SLU = 6;   // entries of a run handled without a loop (longer runs: remainder loop)
+template <bool ZP>
+__device__ __forceinline__ double row_sum_sliced(const BigDev &d, int i, const double *src, const double2 *zp, double beta) {
+    const int P = d.P;
+    const size_t l = (size_t)d.l;
+    const int *sp = d.rptr + i;
+    double acc = 0.0;
+    int ka = sp[0], kae = sp[1];                       // current slice
+    int kb = 0, kbe = 0;                               // next slice
+    if (P > 1) { kb = sp[l]; kbe = sp[l + 1]; }
+    int c[SLU];
+#pragma unroll
+    for (int u = 0; u < SLU; u++) c[u] = ka + u < kae ? d.rcol[ka + u] : -1;
+    for (int ph = 0; ph < P; ph++) {
+        double vx[SLU], vy[SLU];
+#pragma unroll
+        for (int u = 0; u < SLU; u++) {
+            vx[u] = 0.0; vy[u] = 0.0;
+            if (c[u] >= 0) {
+                if constexpr (ZP) { const double2 t = zp[c[u]]; vx[u] = t.x; vy[u] = t.y; }
+                else vx[u] = src[c[u]];
+            }
+        }
+        int cn[SLU];
+#pragma unroll
+        for (int u = 0; u < SLU; u++) cn[u] = kb + u < kbe ? d.rcol[kb + u] : -1;      // ph + 1 < P, else the run is empty
+        int kc = 0, kce = 0;
+        if (ph + 2 < P) { kc = sp[(size_t)(ph + 2) * l]; kce = sp[(size_t)(ph + 2) * l + 1]; }
+#pragma unroll
+        for (int u = 0; u < SLU; u++) {
+            if constexpr (ZP) { const double t = vx[u] + beta * vy[u]; acc = c[u] >= 0 ? acc + t : acc; }
+            else acc = c[u] >= 0 ? acc + vx[u] : acc;
+        }
+        for (int k = ka + SLU; k < kae; k++) {         // rare: a run longer than SLU entries
+            const int cc = d.rcol[k];
+            if constexpr (ZP) { const double2 t = zp[cc]; acc += t.x + beta * t.y; }
+            else acc += src[cc];
+        }
+#pragma unroll
+        for (int u = 0; u < SLU; u++) c[u] = cn[u];
+        ka = kb; kae = kbe; kb = kc; kbe = kce;
+    }
+    return acc;
+}
+
 __global__ void __launch_bounds__(T) big_k_rows(BigDev d, int in, int out, int mode) {
     const BigState *si = d.st + in;
     if (si->halt) { forward_state(d, in, out); return; }
@@ -272,6 +326,13 @@ __global__ void __launch_bounds__(T) big_k_rows(BigDev d, int in, int out, int m
     } else forward_state(d, in, out);
     const double *gs = d.gsrc, *p0 = d.p0;
     (void)pold;
+    if (d.P > 1) {                                   // column-sliced rows (see row_sum_sliced): one row per thread
+        const int i = blockIdx.x * T + threadIdx.x;
+        if (i >= d.l) return;
+        if (mode == 0 || first) d.q[i] = row_sum_sliced<false>(d, i, mode == 0 ? gs : p0, nullptr, 0.0);
+        else d.q[i] = row_sum_sliced<true>(d, i, nullptr, d.zp, beta);
+        return;
+    }
     for (int s = 0; s < d.EPTl; s++) {
         const int i = blockIdx.x * (T * d.EPTl) + s * T + threadIdx.x;
         if (i >= d.l) continue;
@@ -639,7 +700,7 @@ hipError_t big_launch_fin(const BigDev &d, int nv, hipStream_t s) {
 }
 hipError_t big_launch_y(const BigDev &d, int *parity, hipStream_t s) { BIG_LAUNCH(big_k_y, (d.G > d.Gl ? d.G : d.Gl)); return hipGetLastError(); }
 hipError_t big_launch_rhs_cols(const BigDev &d, int *parity, hipStream_t s) { BIG_LAUNCH(big_k_rhs_cols, d.G); return hipGetLastError(); }
-hipError_t big_launch_rows(const BigDev &d, int mode, int *parity, hipStream_t s) { BIG_LAUNCH(big_k_rows, d.Gl, mode); return hipGetLastError(); }
+hipError_t big_launch_rows(const BigDev &d, int mode, int *parity, hipStream_t s) { BIG_LAUNCH(big_k_rows, (d.P > 1 ? d.Glr : d.Gl), mode); return hipGetLastError(); }
 hipError_t big_launch_resid(const BigDev &d, int *parity, hipStream_t s) { BIG_LAUNCH(big_k_resid, d.G); return hipGetLastError(); }
 hipError_t big_launch_pcg_cols(const BigDev &d, int *parity, hipStream_t s) { BIG_LAUNCH(big_k_pcg_cols, d.G); return hipGetLastError(); }
 hipError_t big_launch_pcg_upd(const BigDev &d, int *parity, hipStream_t s) { BIG_LAUNCH(big_k_pcg_upd, d.G); return hipGetLastError(); }

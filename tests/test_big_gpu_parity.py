@@ -7,7 +7,7 @@ import socket
 import numpy as np
 import pytest
 
-from helpers import bits_equal
+from helpers import bits_equal, scripted_fix_vec
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -36,6 +36,43 @@ def test_single_rank_windows_bit_exact(n, seed):
         assert (g.scalar("outer_total"), g.scalar("pcg_total")) == (o.total_outer_iters, o.total_pcg_iters)
         for name in ("rho1", "rho4", "gamma", "dI", "rho4Et", "std_obj", "cur_obj", "cvg1", "cvg2", "obj_val"):
             assert g.scalar(name) == o.scalar(name), name
+
+
+def test_column_sliced_rows_bit_exact(monkeypatch):
+    """The slice-major row storage (the table gathered by E*v is cut into L2-sized column slices, lpbox_big_kernels.hip
+    row_sum_sliced) keeps the ascending column order of every row sum: with slices of 1024 columns (20 slices here, long rows
+    spanning many of them and runs longer than the unrolled six entries inside the dummy-item rows) the iterates are those of
+    the oracle bit for bit, plain windows and an early-fixing window alike."""
+    from lpbox_hip.big import BigLp
+    from lpbox_hip.synth import make_auction_like
+    P = make_auction_like(20000, 2)
+    monkeypatch.setenv("LPBOX_BIG_SLICE_KB", "16")
+    g = BigLp(P)
+    monkeypatch.delenv("LPBOX_BIG_SLICE_KB")
+    g.solve_init()
+    assert int(g.scalar("row_slices")) == 20
+    o = oracle_for(P, g)
+    for (a, b) in ((0, 9), (9, 70)):
+        assert g.solve_iter(a, b) == o.solve_iter(a, b)
+        for name in ("x", "z1", "z2", "z4"):
+            assert bits_equal(g.vec(name), o.vec(name)), name
+        assert (g.scalar("outer_total"), g.scalar("pcg_total")) == (o.total_outer_iters, o.total_pcg_iters)
+    # early-fixing windows on a fresh pair (the fix pass runs E2*x2 through the same row kernel)
+    monkeypatch.setenv("LPBOX_BIG_SLICE_KB", "16")
+    g = BigLp(P)
+    monkeypatch.delenv("LPBOX_BIG_SLICE_KB")
+    g.solve_init()
+    o = oracle_for(P, g)
+    vec, num = np.zeros(P["n"]), 0
+    fixed = 0
+    for w in range(3):
+        assert g.solve_iter_l2f(100 * w, 100 * (w + 1), vec, num) == o.solve_iter_l2f(100 * w, 100 * (w + 1), vec, num)
+        xg, xo = g.get_x_iters_2d(100), o.get_x_iters_2d(100)
+        assert bits_equal(xg, xo), w
+        assert bits_equal(g.vec("z4"), o.vec("z4")) and bits_equal(g.vec("f"), o.vec("f"))
+        vec, num = scripted_fix_vec(xg, lo=0.05, hi=0.95, last=20)
+        fixed += num
+    assert fixed > 0
 
 
 def test_single_rank_full_solve_bit_exact():
