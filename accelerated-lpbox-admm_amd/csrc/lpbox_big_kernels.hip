@@ -17,10 +17,25 @@ namespace {
 constexpr int T = BIG_T;
 #define LEADER (blockIdx.x == 0 && threadIdx.x == 0)
 
+// Streamed once per launch (index lists, pointers, the n-vectors a column owns).  Measured: the non-temporal hint on these makes
+// the chain SLOWER (1.52 -> 1.83 ms per iteration at n = 1e6: a lane's index run shares its 128-byte line with its neighbours'
+// and with its own next loads, which the hint gives up), so it is a diagnostic knob only (LPBOX_BIG_NT).
+#ifndef LPBOX_BIG_NT
+template <typename V> __device__ __forceinline__ V ld_stream(const V *p) { return *p; }
+template <typename V> __device__ __forceinline__ void st_stream(V *p, V v) { *p = v; }
+#else
+template <typename V> __device__ __forceinline__ V ld_stream(const V *p) { return __builtin_nontemporal_load(p); }
+template <typename V> __device__ __forceinline__ void st_stream(V *p, V v) { __builtin_nontemporal_store(v, p); }
+#endif
+
 __device__ __forceinline__ void forward_state(const BigDev &d, int in, int out) {
     if (LEADER) d.st[out] = d.st[in];
 }
 
+// Workgroup partials of NV values -> d.part; big_k_fin reduces them to d.red in a launch of its own.  Measured alternative: the
+// workgroup that arrives last (ticket counter, __threadfence before and after) reduces them inside the producing kernel -- 41
+// launches per iteration fewer, but 3.05 instead of 1.52 ms per iteration at n = 1e6: a device-scope fence per workgroup writes the
+// XCD's L2 back each time.  Dropped.
 template <int NV>
 __device__ __forceinline__ void store_partials(const BigDev &d, double (&v)[NV], double *red, int &parity) {
     block_sum<T, NV>(v, red, parity);
@@ -31,9 +46,39 @@ __device__ __forceinline__ void store_partials(const BigDev &d, double (&v)[NV],
 }
 
 // red[v] = tree over the G workgroup partials of value v (second level of the fixed reduction order)
+constexpr int FIN_U = 16;      // partials per thread held in registers (G <= T * FIN_U = 4096 workgroups, which the host guarantees)
 __global__ void __launch_bounds__(T) big_k_fin(BigDev d, int nv) {
     __shared__ double red[2 * RED_MAXV * RED_MAXW];
     int parity = 0;
+    if (d.G <= T * FIN_U) {
+        // one launch of one workgroup on the critical path of every reduction: all loads of a pair of values are issued before the
+        // first (ordered) addition -- one memory latency instead of one per partial (5.1 -> about 3 us per launch)
+        for (int v0 = 0; v0 < nv; v0 += 2) {
+            const bool two = v0 + 1 < nv;
+            const double *pa = d.part + (size_t)v0 * d.G, *pb = d.part + (size_t)(two ? v0 + 1 : v0) * d.G;
+            double ta[FIN_U], tb[FIN_U];
+#pragma unroll
+            for (int u = 0; u < FIN_U; u++) {
+                const int e = threadIdx.x + u * T;
+                ta[u] = e < d.G ? pa[e] : 0.0;
+                tb[u] = (two && e < d.G) ? pb[e] : 0.0;
+            }
+            double a[1] = {0.0}, b[1] = {0.0};
+#pragma unroll
+            for (int u = 0; u < FIN_U; u++) {
+                const bool in = threadIdx.x + u * T < d.G;
+                a[0] = in ? a[0] + ta[u] : a[0];
+                b[0] = in ? b[0] + tb[u] : b[0];
+            }
+            block_sum<T, 1>(a, red, parity);
+            if (threadIdx.x == 0) d.red[v0] = a[0];
+            if (two) {
+                block_sum<T, 1>(b, red, parity);
+                if (threadIdx.x == 0) d.red[v0 + 1] = b[0];
+            }
+        }
+        return;
+    }
     for (int v = 0; v < nv; v++) {
         const double *p = d.part + (size_t)v * d.G;
         double a[1] = {0.0};
@@ -256,7 +301,7 @@ __device__ __forceinline__ double row_sum_sliced(const BigDev &d, int i, const d
     if (P > 1) { kb = sp[l]; kbe = sp[l + 1]; }
     int c[SLU];
 #pragma unroll
-    for (int u = 0; u < SLU; u++) c[u] = ka + u < kae ? d.rcol[ka + u] : -1;
+    for (int u = 0; u < SLU; u++) c[u] = ka + u < kae ? ld_stream(d.rcol + ka + u) : -1;
     for (int ph = 0; ph < P; ph++) {
         double vx[SLU], vy[SLU];
 #pragma unroll
@@ -269,7 +314,7 @@ __device__ __forceinline__ double row_sum_sliced(const BigDev &d, int i, const d
         }
         int cn[SLU];
 #pragma unroll
-        for (int u = 0; u < SLU; u++) cn[u] = kb + u < kbe ? d.rcol[kb + u] : -1;      // ph + 1 < P, else the run is empty
+        for (int u = 0; u < SLU; u++) cn[u] = kb + u < kbe ? ld_stream(d.rcol + kb + u) : -1;      // ph + 1 < P, else the run is empty
         int kc = 0, kce = 0;
         if (ph + 2 < P) { kc = sp[(size_t)(ph + 2) * l]; kce = sp[(size_t)(ph + 2) * l + 1]; }
 #pragma unroll
@@ -427,20 +472,21 @@ __global__ void __launch_bounds__(T) big_k_pcg_cols(BigDev d, int in, int out) {
         double c = 0.0;
         if (j < d.n_loc) {
             double pj;
-            if (first) pj = d.p0[j];
-            else { pj = d.z[j] + beta * pold[j]; pnew[j] = pj; }                  // p = z + beta p (:319)
+            if (first) pj = ld_stream(d.p0 + j);
+            else { pj = ld_stream(d.z + j) + beta * ld_stream(pold + j); st_stream(pnew + j, pj); }   // p = z + beta p (:319)
             double t = 0.0;
             const int k1 = d.cptr[j + 1];
             int kk = d.cptr[j];
             for (; kk + 4 <= k1; kk += 4) {
-                const double v0 = d.q[d.crow[kk]], v1 = d.q[d.crow[kk + 1]], v2 = d.q[d.crow[kk + 2]], v3 = d.q[d.crow[kk + 3]];
+                const int r0 = ld_stream(d.crow + kk), r1 = ld_stream(d.crow + kk + 1), r2 = ld_stream(d.crow + kk + 2), r3 = ld_stream(d.crow + kk + 3);
+                const double v0 = d.q[r0], v1 = d.q[r1], v2 = d.q[r2], v3 = d.q[r3];
                 t += r4Et * v0; t += r4Et * v1; t += r4Et * v2; t += r4Et * v3;
             }
-            for (; kk < k1; kk++) t += r4Et * d.q[d.crow[kk]];
+            for (; kk < k1; kk++) t += r4Et * d.q[ld_stream(d.crow + kk)];
             double Mp = 0.0;
             Mp += dI * (1.0 * pj);
             Mp += t;
-            d.tmp[j] = Mp;
+            st_stream(d.tmp + j, Mp);
             c = d.live[j] ? pj * Mp : 0.0;
         }
         pc[0] = pc[0] + c;
