@@ -82,6 +82,7 @@ struct lpbox_big {
     bool use_graph = true;
     int G = 0, Gl = 0, EPT = 2, EPTl = 2, P = 1, Glr = 0, kmax = 28, parity = 0;
     bool adaptive = true;
+    int kmargin = 1;                                            // spare PCG launch groups beyond the largest count of the previous batch (LPBOX_BIG_KMARGIN)
     double kernel_ms = 0.0; long long launches = 0, collectives = 0;
     Buf<int> d_rptr, d_rcol, d_cptr, d_crow;
     Buf<double> x, y1, y2, z1, z2, db, pd, dinv, rhs, r, z, tmp, p0, p1, gsrc, y3, z4, df, fy, Ex, q, part, red, xt, xhist, xi_out, gath, flag;
@@ -360,6 +361,7 @@ int lpbox_big_init(lpbox_big_t *h) {
         h->G = (n + BIG_T * h->EPT - 1) / (BIG_T * h->EPT);
         h->EPTl = 2; h->Gl = (l + BIG_T * h->EPTl - 1) / (BIG_T * h->EPTl);
         h->Glr = (l + BIG_T - 1) / BIG_T;
+        if (const char *e = getenv("LPBOX_BIG_KMARGIN")) h->kmargin = std::max(0, atoi(e));
         if (!h->stream) { HIPCHK(hipStreamCreate(&h->stream)); h->own_stream = true; }
         HIPCHK(hipEventCreate(&h->ev0)); HIPCHK(hipEventCreate(&h->ev1));
         HIPCHK(h->d_rptr.alloc((size_t)h->P * l + 1)); HIPCHK(h->d_rcol.alloc(h->nnz)); HIPCHK(h->d_cptr.alloc((size_t)n + 1)); HIPCHK(h->d_crow.alloc(h->nnz));
@@ -413,7 +415,7 @@ static int run_window(lpbox_big *h, const BigDev &d, int iter_end) {
         if (h->hst.halt != BIG_HALT_NONE) break;
         const int remaining = iter_end - h->hst.iter;
         if (remaining <= 0 && !h->hst.have_prev) break;
-        if (h->adaptive && h->hst.outer_total > 0) h->kmax = std::max(4, h->hst.pcg_max + 3);
+        if (h->adaptive && h->hst.outer_total > 0) h->kmax = std::max(4, h->hst.pcg_max + h->kmargin);
         HIPCHK(big_launch_resume(d, 1, &h->parity, h->stream));
         int batch = std::min(std::max(remaining, 0), 16);
         if (h->use_graph && !h->ag && batch >= BIG_ITERS_PER_GRAPH) {

@@ -175,7 +175,7 @@ int finalize(lpbox_t *h) {
     const int big = std::max(nmax, lmax);
     int T = 512;                          // 8 waves with short lists beat 4 waves with long ones also at n = 2000 (512 x 4, register-lean variant)
     if (const char *e = getenv("LPBOX_LP_THREADS")) { int v = atoi(e); if (v == 256 || v == 512 || v == 1024) T = v; }
-    const int max_ept = T == 256 ? 8 : (T == 1024 ? 1 : 4);
+    const int max_ept = T == 256 ? 8 : (T == 1024 ? 2 : 4);
     int EPT = 1;
     while (EPT < max_ept && (long)T * EPT < big) EPT *= 2;
     if ((long)T * EPT < big && T == 512) { T = 256; EPT = 1; while (EPT < 8 && (long)T * EPT < big) EPT *= 2; }

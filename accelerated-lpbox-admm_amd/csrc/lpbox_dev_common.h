@@ -119,6 +119,17 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double *red, int &par
         } else static_assert(NV <= 4, "at most six values");
     }
     __syncthreads();
+    if constexpr (W >= 16) {
+        // 16 waves (128-register budget): lane i takes the partial of wave i mod 16 and the row of 16 lanes runs the balanced tree
+        // over the wave index on DPP -- the same association as the register version below, NV instead of NV * W live values
+        double t[NV];
+#pragma unroll
+        for (int k = 0; k < NV; k++) t[k] = buf[k * RED_MAXW + (lane & (W - 1))];
+#pragma unroll
+        for (int k = 0; k < NV; k++) v[k] = row_allreduce(t[k]);
+        parity ^= 1;
+        return;
+    }
 #ifdef LPBOX_STAGE2_DPP
     double t[NV];
 #pragma unroll

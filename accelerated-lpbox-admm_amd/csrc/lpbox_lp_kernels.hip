@@ -73,6 +73,9 @@ struct LdsLayout {
 // ------------------------------------------------------------------------------------------------
 // gather lists: CAP absolute LDS addresses in registers (+ an LDS index tail for longer lists)
 // ------------------------------------------------------------------------------------------------
+// register-lean variants (cold vectors in memory / LDS): the multi-slot ones and every 16-wave geometry (128 registers per lane)
+__host__ __device__ constexpr bool lp_is_lean(int T, int EPT) { return EPT >= 4 || T == 1024; }
+
 typedef __attribute__((address_space(3))) double lds_double;
 
 __device__ __forceinline__ unsigned lds_addr(const void *p) {
@@ -383,7 +386,7 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
     const size_t on = (size_t)inst * bd.NS, ol = (size_t)inst * bd.LS, oz = (size_t)inst * bd.ZS;
 
     static_assert(!DIRECT || EPT == 1, "the direct x-update is built for the one-slot variants");
-    const LdsLayout L(bd.NS, bd.LS, bd.ZS, EPT >= 4, DIRECT ? bd.HL : 0, DIRECT ? bd.HLD : 0);
+    const LdsLayout L(bd.NS, bd.LS, bd.ZS, lp_is_lean(T, EPT), DIRECT ? bd.HL : 0, DIRECT ? bd.HLD : 0);
     double *gx = (double *)(smem + L.gx);
     double *gl = (double *)(smem + L.gl);       // gl[3*i + c]: c = 0: q = E*p / f - y3, 1: z4, 2: E*y1
     double *red = (double *)(smem + L.red);
@@ -415,7 +418,7 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
     }
 
     // ---- per-thread state ----
-    constexpr bool LEAN = EPT >= 4;              // multi-slot variants: z1, z2, b, pd stay in memory, y1 / y2 are recomputed after the PCG
+    constexpr bool LEAN = lp_is_lean(T, EPT);    // multi-slot variants: z1, z2, b, pd stay in memory, y1 / y2 are recomputed after the PCG
     double x[EPT], dinv[EPT];
     SlotVec<LEAN, EPT, T> z1, z2, b, pd;
     z1.load(bd.z1 + on + tid); z2.load(bd.z2 + on + tid); b.load(bd.b + on + tid); pd.load(bd.pd + on + tid);
@@ -1128,7 +1131,7 @@ __global__ void lp_pack_xiters_kernel(LpBatchDev bd, const int *live_pos, const 
 // launchers
 // ------------------------------------------------------------------------------------------------
 size_t lp_window_lds_bytes(int T, int NS, int LS, int ZS, int HL, int HLD) {
-    return LdsLayout(NS, LS, ZS, NS / T >= 4, HL, HLD).total;
+    return LdsLayout(NS, LS, ZS, lp_is_lean(T, NS / T), HL, HLD).total;
 }
 
 bool lp_direct_supported(int T, int EPT) { return T == 512 && EPT == 1; }     // the default geometry of every n <= 512 batch
@@ -1143,6 +1146,7 @@ bool lp_direct_supported(int T, int EPT) { return T == 512 && EPT == 1; }     //
     else if (T == 512 && EPT == 2) { KERNEL_CALL(512, 2, (Caps<12, 12>), (Caps<12, 8>), (Caps<8, 4>)) }                                      \
     else if (T == 512 && EPT == 4) { KERNEL_CALL(512, 4, (Caps<8, 8, 8, 8>), (Caps<8, 8, 8, 8>), (Caps<4, 4, 4, 4>)) }                        \
     else if (T == 1024 && EPT == 1) { KERNEL_CALL(1024, 1, (Caps<8>), (Caps<8>), (Caps<8>)) }                                                \
+    else if (T == 1024 && EPT == 2) { KERNEL_CALL(1024, 2, (Caps<8, 8>), (Caps<8, 8>), (Caps<4, 4>)) }                                     \
     else return hipErrorInvalidConfiguration;
 
 #define LP_UNPAREN(...) __VA_ARGS__

@@ -56,6 +56,31 @@ def test_first_windows_bit_exact(fixture, idx):
             break
 
 
+@pytest.mark.parametrize("threads,fixture,geometry", [(1024, "lp_100_500_seed0.npz", (1024, 1)), (1024, "lp_500_2000_seed0.npz", (1024, 2)),
+                                                      (256, "lp_100_500_seed0.npz", (256, 2))])
+def test_tuning_geometries_bit_exact(monkeypatch, threads, fixture, geometry):
+    """Workgroup geometries other than the default (LPBOX_LP_THREADS, tuning only): 16 wavefronts in the register-lean form with
+    the second reduction stage on DPP, and 4 wavefronts x 2 slots -- each with its own summation tree, mirrored by the oracle
+    through the exported layout: early-fixing windows and a plain window, every iterate."""
+    I = lp_instances(fixture)[0]
+    monkeypatch.setenv("LPBOX_LP_THREADS", str(threads))
+    g = gpu_solver(I)
+    monkeypatch.delenv("LPBOX_LP_THREADS")
+    cfg = g.batch.config()
+    assert (cfg["threads"], cfg["elems_per_thread"]) == geometry
+    o = oracle_like(g, I)
+    vec, num = np.zeros(I["n"]), 0
+    for w in range(3):
+        assert g.solve_iter_l2f(w * 100, (w + 1) * 100, vec, num) == o.solve_iter_l2f(w * 100, (w + 1) * 100, vec, num)
+        xg, xo = g.get_x_iters_2d(100), o.get_x_iters_2d(100)
+        assert bits_equal(xg, xo), f"window {w}"
+        compare_state(g, o, f"window {w}")
+        vec, num = scripted_fix_vec(xg, lo=0.05, hi=0.95, last=30)
+    assert g.solve_iter(300, 700) == o.solve_iter(300, 700)
+    compare_state(g, o, "plain window")
+    assert g.batch.counters() == (o.total_outer_iters, o.total_pcg_iters)
+
+
 @pytest.mark.parametrize("idx", [0, 1, 2])
 def test_full_plain_solve_bit_exact(idx):
     I = lp_instances("lp_100_500_seed0.npz")[idx]
