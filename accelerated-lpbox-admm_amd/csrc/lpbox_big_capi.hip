@@ -576,10 +576,43 @@ int lpbox_big_get_vec(lpbox_big_t *h, const char *name, double *out, long cap) {
     else if (!strcmp(name, "pd")) src = h->pd.p; else if (!strcmp(name, "b")) src = h->db.p;
     else if (!strcmp(name, "f")) { src = h->df.p; len = h->l; }
     else if (!strcmp(name, "z4")) { src = h->z4.p; len = h->l; } else if (!strcmp(name, "Ex")) { src = h->Ex.p; len = h->l; }
+    else if (!strcmp(name, "live")) {
+        if (cap < len) return lpbox_fail(LPBOX_E_BADARG, "buffer too small");
+        std::vector<uint8_t> lv((size_t)len);
+        HIPCHK(hipMemcpy(lv.data(), h->live.p, (size_t)len, hipMemcpyDeviceToHost));
+        for (long j = 0; j < len; j++) out[j] = lv[j] ? 1.0 : 0.0;
+        return (int)len;
+    }
     else return lpbox_fail(LPBOX_E_BADARG, "unknown vector '%s'", name);
     if (cap < len) return lpbox_fail(LPBOX_E_BADARG, "buffer too small");
     HIPCHK(hipMemcpy(out, src, sizeof(double) * (size_t)len, hipMemcpyDeviceToHost));
     return (int)len;
+}
+
+int lpbox_big_check_infeasible(lpbox_big_t *h, int which) {
+    if (!h || !h->inited) return lpbox_fail(LPBOX_E_STATE, "not initialised");
+    if (h->world != 1) return lpbox_fail(LPBOX_E_UNSUPPORTED, "the infeasibility counts need every column: one rank only");
+    CHK(use_device(h));
+    const int n = h->n_loc, l = h->l;
+    std::vector<double> v(n);
+    std::vector<uint8_t> live(n, 1);
+    if (which == 0) {                                            // LPcpp:1577-1591: current E (live columns), raw iterate
+        if (h->n_live_glob == 0) return 0;
+        HIPCHK(hipMemcpy(v.data(), h->x.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(live.data(), h->live.p, (size_t)n, hipMemcpyDeviceToHost));
+    } else {                                                     // LPcpp:1593-1612: original E, binary full-length solution
+        int rc = lpbox_big_get_x_sol(h, v.data());
+        if (rc < 0) return rc;
+    }
+    // rows in ascending column order (the slices of the row storage follow each other in column order)
+    std::vector<double> s(l, 0.0);
+    for (int ph = 0; ph < h->P; ph++)
+        for (int i = 0; i < l; i++)
+            for (int k = h->rptr[(size_t)ph * l + i]; k < h->rptr[(size_t)ph * l + i + 1]; k++)
+                if (live[h->rcol[k]]) s[i] += 1.0 * v[h->rcol[k]];
+    int inf = 0;
+    for (int i = 0; i < l; i++) if (!(s[i] <= 1.0)) inf++;          // the reference compares with 1.0, not with f
+    return inf;
 }
 
 int lpbox_big_get_scalar(lpbox_big_t *h, const char *name, double *out) {

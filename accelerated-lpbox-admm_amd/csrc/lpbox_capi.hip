@@ -1066,6 +1066,21 @@ int lpbox_cur_bin_obj(lpbox_t *h, int idx, double *out) {
     return LPBOX_OK;
 }
 
+int lpbox_get_problem_lp(lpbox_t *h, int idx, int *n, int *l, int *nnz, int *colptr, int *rowidx, double *b, double *f) {
+    int rc = check_idx(h, idx);
+    if (rc) return rc;
+    const LpInstance &I = h->inst[idx];
+    if (!I.set) return fail(LPBOX_E_STATE, "instance %d has no problem (call read_File / set_problem first)", idx);
+    if (n) *n = I.n;
+    if (l) *l = I.l;
+    if (nnz) *nnz = I.nnz;
+    if (colptr) std::copy(I.colptr.begin(), I.colptr.end(), colptr);
+    if (rowidx) std::copy(I.rowidx.begin(), I.rowidx.end(), rowidx);
+    if (b) std::copy(I.b.begin(), I.b.end(), b);
+    if (f) std::copy(I.f_org.begin(), I.f_org.end(), f);
+    return LPBOX_OK;
+}
+
 int lpbox_check_infeasible_lpbox(lpbox_t *h, int idx) {                     // LPcpp:1577-1591: rows of the CURRENT E with (E x)_i > 1
     int rc = check_idx(h, idx);
     if (rc) return rc;

@@ -30,6 +30,8 @@ SYMBOLS = {
     "lpbox_set_problem_lp": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _ip, _ip, C.c_void_p, _dp, C.c_void_p]),
     "lpbox_read_files_lp": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_int]),
     "lpbox_read_file": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int]),
+    "lpbox_get_problem_lp": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p]),
     "lpbox_init": (C.c_int, [C.c_void_p]),
     "lpbox_iterate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "lpbox_iterate_l2f": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p]),
@@ -90,6 +92,7 @@ SYMBOLS = {
     "lpbox_big_get_x": (C.c_int, [C.c_void_p, _dp]),
     "lpbox_big_get_vec": (C.c_int, [C.c_void_p, C.c_char_p, _dp, C.c_long]),
     "lpbox_big_get_scalar": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]),
+    "lpbox_big_check_infeasible": (C.c_int, [C.c_void_p, C.c_int]),
     "lpbox_bqp_create": (C.c_void_p, [C.c_int]),
     "lpbox_bqp_destroy": (None, [C.c_void_p]),
     "lpbox_bqp_preset": (C.c_int, [C.c_void_p, C.c_int]),

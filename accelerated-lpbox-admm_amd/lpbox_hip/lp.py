@@ -82,6 +82,16 @@ class LpBatch:
         r = os.fsencode(root) if root is not None else None
         check(self._L.lpbox_read_file(self._h, idx, r, int(i), int(k), int(j)), "lpbox_read_file")
 
+    def get_problem(self, idx=0):
+        """The instance as set_problem / read_file left it in the handle: dict(n, l, colptr, rowidx, b, f)."""
+        n, l, nnz = C.c_int(), C.c_int(), C.c_int()
+        check(self._L.lpbox_get_problem_lp(self._h, idx, C.byref(n), C.byref(l), C.byref(nnz), None, None, None, None), "lpbox_get_problem_lp")
+        colptr, rowidx = np.zeros(n.value + 1, np.int32), np.zeros(max(nnz.value, 1), np.int32)
+        b, f = np.zeros(n.value), np.zeros(l.value)
+        check(self._L.lpbox_get_problem_lp(self._h, idx, None, None, None, colptr.ctypes.data_as(C.c_void_p), rowidx.ctypes.data_as(C.c_void_p),
+                                           b.ctypes.data_as(C.c_void_p), f.ctypes.data_as(C.c_void_p)), "lpbox_get_problem_lp")
+        return dict(n=n.value, l=l.value, colptr=colptr, rowidx=rowidx[:nnz.value], b=b, f=f)
+
     # ---- solver ----
     def solve_init(self):
         return check(self._L.lpbox_init(self._h), "lpbox_init")
@@ -246,8 +256,99 @@ class LpBatch:
         return v.value
 
 
+ONCHIP_MAX = 2048       # storage positions of the one-workgroup-per-instance kernel (512 threads x 4 slots): max(n, l) beyond it cannot stay on a CU
+
+
+class _LargeInstance:
+    """The slice of LpBatch's surface that PyLPboxADMMsolver uses, served by the large-instance path (lpbox_big_*, one rank): the
+    instance lives in HBM and an iteration is a chain of kernels instead of one persistent workgroup.  Same algorithm, same
+    quirks, its own (two-level) summation order -- bit-exact against the oracle in that order (tests/test_dropin_large_gpu.py)."""
+
+    B = 1
+    can_record = False       # the plain loop's per-iteration dump (print_info 2/3) is not staged on this path
+
+    def __init__(self, problem, device=None):
+        from .big import BigLp
+        self._g = BigLp(problem, device=0 if device is None else int(device))
+        self._org_n = int(problem["n"])
+        self._l = int(problem["l"])
+
+    def close(self):
+        self._g.close()
+
+    def solve_init(self):
+        return self._g.solve_init()
+
+    def set_record(self, on=True):
+        return None
+
+    def solve_iter(self, i, j):
+        return np.array([self._g.solve_iter(_as_int(i, "i"), _as_int(j, "j"))], np.int32)
+
+    def solve_iter_l2f(self, i, j, vecs=None, nums=None):
+        num = 0 if nums is None else int(np.asarray(nums).ravel()[0])
+        vec = None if (vecs is None or num == 0) else np.asarray(vecs, np.float64).ravel()
+        return np.array([self._g.solve_iter_l2f(_as_int(i, "i"), _as_int(j, "j"), vec, num)], np.int32)
+
+    def get_n(self, idx=0):
+        return self._g.get_n()
+
+    def get_org_n(self, idx=0):
+        return self._org_n
+
+    def get_l(self, idx=0):
+        return self._l
+
+    def get_iter(self, idx=0):
+        return int(self._g.scalar("iter"))
+
+    def get_x_iters_2d(self, ws, idx=0):
+        return self._g.get_x_iters_2d(_as_int(ws, "ws"))
+
+    def get_x_sol(self, idx=0):
+        return self._g.local_x_sol()
+
+    def get_final_x_sol(self, idx=0):
+        return self._g.local_x()[self._g.vec("live")[: self._org_n] != 0]          # raw live x, compact order (LPcpp:1668-1685)
+
+    def cal_obj(self, idx=0):
+        return self._g.cal_Obj()
+
+    def cur_bin_obj(self, idx=0):
+        return self._g.scalar("cur_obj")
+
+    def check_infeasible_lpbox(self, idx=0):
+        return check(self._g._L.lpbox_big_check_infeasible(self._g._h, 0), "lpbox_big_check_infeasible")
+
+    def check_infeasible_l2f(self, idx=0):
+        return check(self._g._L.lpbox_big_check_infeasible(self._g._h, 1), "lpbox_big_check_infeasible")
+
+    def stop(self, idx=0):
+        return int(self._g.scalar("stop")), int(self._g.scalar("plain_iter_p1"))
+
+    def counters(self, idx=0):
+        return int(self._g.scalar("outer_total")), int(self._g.scalar("pcg_total"))
+
+    def debug_scalar(self, name, idx=0):
+        return self._g.scalar(name)
+
+    def debug_vec(self, name, idx=0):
+        return self._g.vec(name)
+
+    def config(self):
+        """Reduction geometry of this path (what the oracle needs to mirror it): threads per workgroup and columns per workgroup."""
+        return dict(threads=int(self._g.scalar("threads")), chunk=int(self._g.scalar("chunk")), large=True)
+
+    @property
+    def big(self):
+        return self._g
+
+
 class PyLPboxADMMsolver:
     """Same surface as the reference's `cdef class PyLPboxADMMsolver` (LP pyx:7-76), one instance per object.
+
+    Instances up to max(n, l) = 2048 run on the on-chip kernel (one workgroup per instance); larger ones are handed to the
+    large-instance path at solve_init, transparently (`large` tells which; the reference has no size limit, LPcpp:2446-2545).
 
     print_info: 0 quiet, 1 print fix sizes (LPcpp:1188-1190).  Set `verbose = True` to echo the reference's
     stdout messages (constructor banner LPcpp:478, stop reasons :935/:984, fix summary :1333).
@@ -271,8 +372,16 @@ class PyLPboxADMMsolver:
         if self.verbose:
             print("Object with fix_info is created!")
 
+    def _small(self):
+        """A new problem on an object that had been routed to the large path starts from the on-chip handle again."""
+        if not isinstance(self._b, LpBatch):
+            self._b.close()
+            self._b = LpBatch(batch=1, print_info=self.print_info)
+        return self._b
+
     # LP pyx:16-17
     def read_File(self, i, k, j):
+        self._small()
         root = self.data_root or os.environ.get("LPBOX_DATA_ROOT")
         self._b.read_file(0, _as_int(i, "i"), _as_int(k, "k"), _as_int(j, "j"), root)
         self._file_id = (int(i), int(k), int(j))
@@ -281,16 +390,33 @@ class PyLPboxADMMsolver:
 
     # extension: hand the problem over in memory instead of through the instance files
     def set_problem(self, n, l, colptr, rowidx, b, f=None):
-        self._b.set_problem(0, n, l, colptr, rowidx, b, f)
+        self._small().set_problem(0, n, l, colptr, rowidx, b, f)
 
     # LP pyx:19-20
     def solve_init(self):
+        if isinstance(self._b, LpBatch):
+            P = self._b.get_problem(0)
+            fits = max(P["n"], P["l"]) <= ONCHIP_MAX
+            if fits:
+                try:
+                    return self._b.solve_init()
+                except LpboxError as e:                    # fits the register slots but not the CU's 160 KiB of LDS (very dense E)
+                    if "of LDS" not in str(e):
+                        raise
+            small = self._b                                # does not fit one CU: same algorithm on the multi-kernel path
+            self._b = _LargeInstance(P)
+            small.close()
         return self._b.solve_init()
+
+    @property
+    def large(self):
+        """True once solve_init has routed this instance to the large-instance path."""
+        return isinstance(self._b, _LargeInstance)
 
     # LP pyx:22-23
     def solve_iter(self, i, j):
         out_dir = self._xiter_dir()
-        dump = out_dir is not None and self.print_info in (2, 3) and _as_int(j, "j") > _as_int(i, "i")
+        dump = out_dir is not None and self.print_info in (2, 3) and _as_int(j, "j") > _as_int(i, "i") and getattr(self._b, "can_record", True)
         self._b.set_record(dump)
         t0 = time.perf_counter()
         ret = int(self._b.solve_iter(i, j)[0])

@@ -62,6 +62,11 @@ int lpbox_read_files_lp(lpbox_t *h, int idx, const char *path_C, const char *pat
  * root NULL = the reference's "../cython_solver/data" relative to the CWD (LPcpp:2451). */
 int lpbox_read_file(lpbox_t *h, int idx, const char *root, int i, int k, int j);
 
+/* The instance as set_problem / readFile left it in the handle (what LPcpp:2446-2545 leaves in the solver's members n, l, E, b, f): sizes
+ * always, arrays where the pointer is not NULL (colptr n+1, rowidx nnz, b n, f l).  Used by the Python class to hand an instance
+ * that exceeds the on-chip kernel (max(n, l) > 2048) over to the large-instance path. */
+int lpbox_get_problem_lp(lpbox_t *h, int idx, int *n, int *l, int *nnz, int *colptr, int *rowidx, double *b, double *f);
+
 /* ---- solver (whole batch per call) ------------------------------------------------------------ */
 /* LP pxd:10 `int ADMM_lp_iters_init()` (LPcpp:489-763).  Returns 1 like the reference. */
 int lpbox_init(lpbox_t *h);
@@ -225,7 +230,10 @@ int lpbox_big_get_x_iters_device(lpbox_big_t *h, int ws, void **dev_ptr, int *ro
 int lpbox_big_get_x_sol(lpbox_big_t *h, double *out_local);                     /* binary: fixed value / rounded x (LPcpp:1648-1666) */
 int lpbox_big_cal_obj(lpbox_big_t *h, double *out);                             /* sum_fix_obj + cur_obj (LPcpp:1630-1642) */
 int lpbox_big_get_x(lpbox_big_t *h, double *out_local);                         /* this rank's slice of x_sol */
-int lpbox_big_get_vec(lpbox_big_t *h, const char *name, double *out, long cap); /* "x","z1","z2","pd" (local), "z4","Ex" (rows) */
+int lpbox_big_get_vec(lpbox_big_t *h, const char *name, double *out, long cap); /* "x","z1","z2","pd","live" (local), "z4","Ex" (rows) */
+/* LP pxd:20 / :21 on the large path, one rank only: which = 0 check_infeasible_lpbox (LPcpp:1577-1591: rows of the CURRENT E, live
+ * columns, raw iterate), 1 check_infeasible_l2f (LPcpp:1593-1612: original E times the binary full-length solution); count >= 0. */
+int lpbox_big_check_infeasible(lpbox_big_t *h, int which);
 int lpbox_big_get_scalar(lpbox_big_t *h, const char *name, double *out);        /* "cur_obj","iter","stop","outer_total","pcg_total",... */
 
 /* ---- generic constrained binary QP: min x'Ax + b'x  s.t.  Cx = d, Ex <= f, x in {0,1}^n -----------------------------------------

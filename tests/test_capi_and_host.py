@@ -79,6 +79,27 @@ def test_host_side_validation_and_no_cpu_fallback():
             s.solve_init()                    # the product path fails loudly without its GPU
 
 
+def test_instance_comes_back_out_of_the_handle():
+    """lpbox_get_problem_lp returns what set_problem / readFile left in the handle (the hand-over of an oversize instance to the
+    large-instance path starts from it): arrays equal to the input, default f = ones, the file route equal to the fixture."""
+    from lpbox_hip.lp import LpBatch, PyLPboxADMMsolver
+    I = lp_instances("lp_100_500_seed0.npz")[0]
+    b = LpBatch(batch=2)
+    b.set_problem(1, I["n"], I["l"], I["colptr"], I["rowidx"], I["b"])
+    P = b.get_problem(1)
+    assert (P["n"], P["l"]) == (I["n"], I["l"])
+    assert np.array_equal(P["colptr"], I["colptr"]) and np.array_equal(P["rowidx"], I["rowidx"])
+    assert np.array_equal(P["b"], I["b"]) and np.array_equal(P["f"], np.ones(I["l"]))
+    from lpbox_hip.lp import LpboxError
+    with pytest.raises(LpboxError, match="no problem"):
+        b.get_problem(0)
+    s = PyLPboxADMMsolver(0)
+    s.data_root = GOLDEN
+    s.read_File(1, 100, 500)
+    Q = s.batch.get_problem(0)
+    assert np.array_equal(Q["colptr"], I["colptr"]) and np.array_equal(Q["rowidx"], I["rowidx"]) and np.array_equal(Q["b"], I["b"])
+
+
 def test_shard_range_partitions():
     from lpbox_hip.dist import shard_range
     for total in (0, 1, 7, 256, 2048):
