@@ -3,7 +3,7 @@
 // convergence, infeasible-constraint count, wall-clock).  Adds a machine-readable RESULT line for the tests.
 //   usage: lp_solve <i> <k> <j> [max_iters=20000] [window=0]
 // window > 0 runs the early-fixing entry point in windows of that many iterations without fixing anything (exercises
-// ADMM_lp_iters_l2f / get_x_iters_d from C++).
+// ADMM_lp_iters_l2f / get_x_iters_d from C++); window < 0 runs the rule-based early fixing ADMM_lp_iters_fix over [0, max_iters).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -22,7 +22,8 @@ int main(int argc, char **argv) {
         solver.ADMM_lp_iters_init();
         int ret = 0;
         double checksum = 0;
-        if (window <= 0) ret = solver.ADMM_lp_iters(0, max_iters);
+        if (window < 0) ret = solver.ADMM_lp_iters_fix(0, max_iters);
+        else if (window == 0) ret = solver.ADMM_lp_iters(0, max_iters);
         else
             for (int a = 0; a < max_iters && !ret; a += window) {
                 ret = solver.ADMM_lp_iters_l2f(a, a + window, nullptr, 0);
@@ -35,8 +36,8 @@ int main(int argc, char **argv) {
         const double *sol = solver.get_x_sol();
         long ones = 0;
         for (int v = 0; v < solver.get_org_n(); v++) ones += sol[v] != 0;
-        printf("RESULT ret=%d objective=%.17g iterations=%lld stop=%d infeasible=%d ones=%ld n=%d large=%d checksum=%.17g\n", ret, -solver.cal_obj(),
-               solver.outer_iterations(), solver.stop_reason(), infeasible, ones, solver.get_org_n(), solver.on_large_path() ? 1 : 0, checksum);
+        printf("RESULT ret=%d objective=%.17g iterations=%lld stop=%d infeasible=%d ones=%ld n=%d live=%d large=%d checksum=%.17g\n", ret, -solver.cal_obj(),
+               solver.outer_iterations(), solver.stop_reason(), infeasible, ones, solver.get_org_n(), solver.get_n(), solver.on_large_path() ? 1 : 0, checksum);
         printf("Time elapsed: %gs;\n", secs);
     } catch (const std::exception &e) {
         fprintf(stderr, "lp_solve: %s\n", e.what());

@@ -68,6 +68,25 @@ def test_cxx_driver_equals_python_class_and_oracle(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cxx_rule_based_fixing_equals_python(tmp_path):
+    """ADMM_lp_iters_fix through the C++ class (LPcpp:1689-2286, repaired semantics of DESIGN.md section 16) takes the decisions of
+    PyLPboxADMMsolver.solve_iter_fix, which tests/test_lp_fix_rule_gpu.py holds against the oracle: same fixes, same end state."""
+    from lpbox_hip.lp import PyLPboxADMMsolver
+    exe = build_driver(tmp_path)
+    res, _ = run_driver(exe, GOLDEN, 1, 100, 500, 1500, -1)
+    g = PyLPboxADMMsolver(0)
+    g.data_root = GOLDEN
+    g.read_File(1, 100, 500)
+    g.solve_init()
+    ret = g.solve_iter_fix(0, 1500)
+    assert int(res["ret"]) == ret
+    assert int(res["live"]) == g.get_n() and g.get_n() < 500
+    assert float(res["objective"]) == -g.cal_Obj()
+    assert int(res["iterations"]) == g.batch.counters()[0]
+    assert int(res["ones"]) == int(g.get_x_sol().sum())
+
+
+@pytest.mark.gpu
 def test_cxx_driver_routes_an_oversize_instance(tmp_path):
     from lpbox_hip.lp import PyLPboxADMMsolver
     from lpbox_hip.synth import make_auction_like, write_instance_files
