@@ -110,13 +110,15 @@ def _rank(rank, world, port, q, iters):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_variable_sharded_ranks_bit_exact_against_oracle_rank_model(world):
+@pytest.mark.parametrize("world,slice_kb", [(2, None), (3, None), (2, 8)])
+def test_variable_sharded_ranks_bit_exact_against_oracle_rank_model(world, slice_kb, monkeypatch):
     """W ranks (all on the test box's one GPU, contributions exchanged over gloo) against the oracle's model of the rank partition
     (per-rank sums added in rank order, oracle lpo_set_ranks): every iterate bit for bit -- not a comparison with a 1-rank HIP run."""
     import torch.multiprocessing as mp
     from lpbox_hip.synth import make_auction_like
     iters = 12
+    if slice_kb is not None:                                    # the column-sliced row storage inside every rank's shard (3 slices of 1 000 of the 3 000 local columns)
+        monkeypatch.setenv("LPBOX_BIG_SLICE_KB", str(slice_kb))
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
