@@ -46,46 +46,10 @@ __device__ __forceinline__ void store_partials(const BigDev &d, double (&v)[NV],
 }
 
 // red[v] = tree over the G workgroup partials of value v (second level of the fixed reduction order)
-constexpr int FIN_U = 16;      // partials per thread held in registers (G <= T * FIN_U = 4096 workgroups, which the host guarantees)
 __global__ void __launch_bounds__(T) big_k_fin(BigDev d, int nv) {
     __shared__ double red[2 * RED_MAXV * RED_MAXW];
     int parity = 0;
-    if (d.G <= T * FIN_U) {
-        // one launch of one workgroup on the critical path of every reduction: all loads of a pair of values are issued before the
-        // first (ordered) addition -- one memory latency instead of one per partial (5.1 -> about 3 us per launch)
-        for (int v0 = 0; v0 < nv; v0 += 2) {
-            const bool two = v0 + 1 < nv;
-            const double *pa = d.part + (size_t)v0 * d.G, *pb = d.part + (size_t)(two ? v0 + 1 : v0) * d.G;
-            double ta[FIN_U], tb[FIN_U];
-#pragma unroll
-            for (int u = 0; u < FIN_U; u++) {
-                const int e = threadIdx.x + u * T;
-                ta[u] = e < d.G ? pa[e] : 0.0;
-                tb[u] = (two && e < d.G) ? pb[e] : 0.0;
-            }
-            double a[1] = {0.0}, b[1] = {0.0};
-#pragma unroll
-            for (int u = 0; u < FIN_U; u++) {
-                const bool in = threadIdx.x + u * T < d.G;
-                a[0] = in ? a[0] + ta[u] : a[0];
-                b[0] = in ? b[0] + tb[u] : b[0];
-            }
-            block_sum<T, 1>(a, red, parity);
-            if (threadIdx.x == 0) d.red[v0] = a[0];
-            if (two) {
-                block_sum<T, 1>(b, red, parity);
-                if (threadIdx.x == 0) d.red[v0 + 1] = b[0];
-            }
-        }
-        return;
-    }
-    for (int v = 0; v < nv; v++) {
-        const double *p = d.part + (size_t)v * d.G;
-        double a[1] = {0.0};
-        for (int e = threadIdx.x; e < d.G; e += T) a[0] = a[0] + p[e];
-        block_sum<T, 1>(a, red, parity);
-        if (threadIdx.x == 0) d.red[v] = a[0];
-    }
+    fin_reduce<T>(d.part, d.G, nv, d.red, red, parity);
 }
 
 __global__ void __launch_bounds__(T) big_k_init(BigDev d, double c1) {          // ADMM_lp_iters_init LPcpp:489-763

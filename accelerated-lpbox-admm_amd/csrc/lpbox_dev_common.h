@@ -165,4 +165,47 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double *red, int &par
     parity ^= 1;
 }
 
+// Second level of the fixed reduction order, shared by the multi-kernel paths (large LP, generic BQP): out[v] = block tree over
+// (thread t: partials t, t + T, ... of value v in ascending order), partials of value v at part[v * G ..].  Runs as ONE workgroup on
+// the critical path of every reduction, so for 2 T < G <= T * FIN_U all loads of a pair of values are issued before the first (ordered)
+// addition -- one memory latency instead of one per partial (5.1 -> about 3 us per launch at G = 1954).
+constexpr int FIN_U = 16;
+template <int T>
+__device__ __forceinline__ void fin_reduce(const double *part, int G, int nv, double *out, double *red, int &parity) {
+    if (G > 2 * T && G <= T * FIN_U) {          // (with one or two partials per thread the plain loop below is the shorter program: A/B on the generic path)
+        for (int v0 = 0; v0 < nv; v0 += 2) {
+            const bool two = v0 + 1 < nv;
+            const double *pa = part + (size_t)v0 * G, *pb = part + (size_t)(two ? v0 + 1 : v0) * G;
+            double ta[FIN_U], tb[FIN_U];
+#pragma unroll
+            for (int u = 0; u < FIN_U; u++) {
+                const int e = threadIdx.x + u * T;
+                ta[u] = e < G ? pa[e] : 0.0;
+                tb[u] = (two && e < G) ? pb[e] : 0.0;
+            }
+            double a[1] = {0.0}, b[1] = {0.0};
+#pragma unroll
+            for (int u = 0; u < FIN_U; u++) {
+                const bool in = (int)threadIdx.x + u * T < G;
+                a[0] = in ? a[0] + ta[u] : a[0];
+                b[0] = in ? b[0] + tb[u] : b[0];
+            }
+            block_sum<T, 1>(a, red, parity);
+            if (threadIdx.x == 0) out[v0] = a[0];
+            if (two) {
+                block_sum<T, 1>(b, red, parity);
+                if (threadIdx.x == 0) out[v0 + 1] = b[0];
+            }
+        }
+        return;
+    }
+    for (int v = 0; v < nv; v++) {
+        const double *p = part + (size_t)v * G;
+        double a[1] = {0.0};
+        for (int e = threadIdx.x; e < G; e += T) a[0] = a[0] + p[e];
+        block_sum<T, 1>(a, red, parity);
+        if (threadIdx.x == 0) out[v] = a[0];
+    }
+}
+
 }  // namespace

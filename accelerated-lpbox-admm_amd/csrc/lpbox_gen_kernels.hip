@@ -33,13 +33,7 @@ __device__ __forceinline__ double eigen_res(double tmp) { double r = 0.0; r += 1
 __global__ void __launch_bounds__(T) gen_k_fin(GenDev d, int nv) {
     __shared__ double red[2 * RED_MAXV * RED_MAXW];
     int parity = 0;
-    for (int v = 0; v < nv; v++) {
-        const double *p = d.part + (size_t)v * d.G;
-        double a[1] = {0.0};
-        for (int e = threadIdx.x; e < d.G; e += T) a[0] = a[0] + p[e];
-        block_sum<T, 1>(a, red, parity);
-        if (threadIdx.x == 0) d.red[v] = a[0];
-    }
+    fin_reduce<T>(d.part, d.G, nv, d.red, red, parity);
 }
 
 // A x for row j with x read through `ld` (ascending columns, diagonal included)
