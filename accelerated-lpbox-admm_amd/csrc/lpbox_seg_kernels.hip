@@ -30,13 +30,24 @@ __device__ __forceinline__ double *part_ptr(const SegDev &d, int phase, int v) {
 }
 
 // every workgroup: total of the G workgroup partials of NV values (second level of the fixed tree)
+// This sits at the head of every consumer kernel, i.e. on the critical path of the launch chain: the host keeps G <= 2 T, so a thread
+// has at most two partials per value, and all of them (NV x 2 loads) are requested before the first addition -- one memory latency
+// instead of up to 2 NV dependent ones.  Same per-thread order (partial t, then t + T), same tree.
 template <int NV>
 __device__ __forceinline__ void final_sums(const SegDev &d, int phase, double (&out)[NV], double *red, int &parity) {
+    const int e0 = threadIdx.x, e1 = threadIdx.x + T;
+    double t0[NV], t1[NV];
 #pragma unroll
     for (int k = 0; k < NV; k++) {
         const double *p = part_ptr(d, phase, k);
+        t0[k] = e0 < d.G ? p[e0] : 0.0;
+        t1[k] = e1 < d.G ? p[e1] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
         double a = 0.0;
-        for (int e = threadIdx.x; e < d.G; e += T) a = a + p[e];
+        if (e0 < d.G) a = a + t0[k];
+        if (e1 < d.G) a = a + t1[k];
         out[k] = a;
     }
     block_sum<T, NV>(out, red, parity);
