@@ -335,24 +335,42 @@ __device__ __forceinline__ double uniform_f64(double v) {
     return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
 
-// One value per slot of the thread, either in registers (N slots) or -- multi-slot variants, where the register file is the scarce
-// resource -- left in its HBM/L2 pool and touched at its few use sites per outer iteration (vectors the PCG loop never reads).
+// One value per slot of the thread.  MODE 0: in registers for the whole launch.  The register-lean variants keep the vectors the PCG
+// loop never reads out of the register file WHILE THAT LOOP RUNS: MODE 1 leaves the vector in its HBM/L2 pool and touches it at its
+// (rare) use sites (pd: read and written only when rho changes); MODE 2 holds it in registers outside the PCG loop -- park() stores it
+// right before the loop, unpark() brings it back right after, all slots in one batch of loads -- so the outer phases see registers
+// (z1, z2, b: a load issued behind a store to a possibly aliasing address has to wait for the store on this target, which made
+// every get-after-set of the memory-backed form a full memory round trip: 8 of them per outer iteration in the dual update alone).
 // Every thread only ever touches its own elements, so no synchronisation is involved.
-template <bool MEM, int N, int STRIDE>
+template <int MODE, int N, int STRIDE>
 struct SlotVec {
-    double r[MEM ? 1 : N];
+    double r[MODE == 1 ? 1 : N];
     double *g;                                   // this thread's element of slot 0; slot s is STRIDE elements further
     __device__ __forceinline__ void load(double *base) {
         g = base;
-        if constexpr (!MEM) {
+        if constexpr (MODE != 1) {
 #pragma unroll
             for (int s = 0; s < N; s++) r[s] = base[s * STRIDE];
         }
     }
-    __device__ __forceinline__ double get(int s) const { if constexpr (MEM) return g[s * STRIDE]; else return r[s]; }
-    __device__ __forceinline__ void set(int s, double v) { if constexpr (MEM) g[s * STRIDE] = v; else r[s] = v; }
+    __device__ __forceinline__ double get(int s) const { if constexpr (MODE == 1) return g[s * STRIDE]; else return r[s]; }
+    __device__ __forceinline__ void set(int s, double v) { if constexpr (MODE == 1) g[s * STRIDE] = v; else r[s] = v; }
+    __device__ __forceinline__ void park(bool dirty = true) {          // MODE 2: registers -> memory (nothing to write for a vector that never changes)
+        if constexpr (MODE == 2) {
+            if (dirty) {
+#pragma unroll
+                for (int s = 0; s < N; s++) g[s * STRIDE] = r[s];
+            }
+        }
+    }
+    __device__ __forceinline__ void unpark() {                         // MODE 2: memory -> registers
+        if constexpr (MODE == 2) {
+#pragma unroll
+            for (int s = 0; s < N; s++) r[s] = g[s * STRIDE];
+        }
+    }
     __device__ __forceinline__ void store() const {
-        if constexpr (!MEM) {
+        if constexpr (MODE != 1) {
 #pragma unroll
             for (int s = 0; s < N; s++) g[s * STRIDE] = r[s];
         }
@@ -420,7 +438,8 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
     // ---- per-thread state ----
     constexpr bool LEAN = lp_is_lean(T, EPT);    // multi-slot variants: z1, z2, b, pd stay in memory, y1 / y2 are recomputed after the PCG
     double x[EPT], dinv[EPT];
-    SlotVec<LEAN, EPT, T> z1, z2, b, pd;
+    SlotVec<LEAN ? 2 : 0, EPT, T> z1, z2, b;
+    SlotVec<LEAN ? 1 : 0, EPT, T> pd;
     z1.load(bd.z1 + on + tid); z2.load(bd.z2 + on + tid); b.load(bd.b + on + tid); pd.load(bd.pd + on + tid);
     // Esq_diag_j = sum of squared entries of column j (LPcpp:2378-2390) = its length (entries are 1.0): needed only when the
     // diagonal is rebuilt (iteration 0, a fix, a rho update), so it is re-read from the layout instead of living in a register
@@ -738,6 +757,7 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
                 for (int s = 0; s < EPT; s++) { const double v = pd.get(s); dinv[s] = (v != 0.0) ? 1.0 / v : 1.0; }
                 rhoUpdated = 0;
             }
+            z1.park(); z2.park(); b.park(false);                      // register-lean variants: out of the register file while the PCG runs
             STAMP(1)
             // ---------------- PCG (LPcpp:251-335) on (dI*I + rho4 E^T E) x = rhs ----------------
             double xt[EPT];
@@ -945,6 +965,7 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
             }
             }   // PCG
             STAMP(11)
+            z1.unpark(); z2.unpark(); b.unpark();                     // ... and back, one batch of loads
             last_pcg = k_it;
             pcg_total += k_it;
             if (pcg_fail) stop = LP_STOP_PCG;
