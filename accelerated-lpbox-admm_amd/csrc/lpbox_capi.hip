@@ -250,11 +250,37 @@ int finalize(lpbox_t *h) {
         struct Task { int row, g, G; };
         std::vector<Task> task_of_slot(NS, Task{-1, 0, 1});
         std::vector<int> slot_of_row(I.l, 0);          // storage slot of lane 0 of the row's task group (lanes are consecutive)
+        // Blocks of 64 consecutive (sorted) tasks -> (wave, slot).  A wave walks every slot to the longest list of its 64 lanes, in chunks
+        // of 4 gathers, and the phase ends when the slowest wave does; the sort is by (lanes per row, list length), so the block maxima are
+        // not monotone and the snake deal left the waves of a multi-slot layout up to 35 % apart (j=500/k=2000: 24 ... 44 chunks-of-4
+        // entries per wave).  Multi-slot variants therefore deal the blocks longest-first to the least loaded wave that has a free slot.
+        // Where a row's task sits changes nothing in the arithmetic (a row sum is the same sum in any lane), only the time.
+        std::vector<int> row_block_base;
+        if (!nosort && h->EPT >= 2 && getenv("LPBOX_LP_SNAKEROWS") == nullptr) {
+            long ntask = 0;
+            for (int r = 0; r < I.l; r++) ntask += I.rowG[r];
+            const int nb = (int)((ntask + 63) / 64);
+            std::vector<int> bmax(nb, 0);
+            long qq = 0;
+            for (int r : rorder) { for (int g = 0; g < I.rowG[r]; g++, qq++) bmax[qq / 64] = std::max(bmax[qq / 64], chain(r)); }
+            std::vector<int> border(nb);
+            for (int b2 = 0; b2 < nb; b2++) border[b2] = b2;
+            auto cost = [&](int b2) { return (bmax[b2] + 3) / 4 * 4; };
+            std::stable_sort(border.begin(), border.end(), [&](int a, int c) { return cost(a) > cost(c); });
+            std::vector<int> load(W, 0), used(W, 0);
+            row_block_base.assign(nb, 0);
+            for (int b2 : border) {
+                int best = -1;
+                for (int w = 0; w < W; w++) if (used[w] < h->EPT && (best < 0 || load[w] < load[best])) best = w;
+                row_block_base[b2] = used[best] * h->T + best * 64;
+                used[best]++; load[best] += cost(b2);
+            }
+        }
         int q = 0, max_chain = 1;
         for (int r : rorder) {
             max_chain = std::max(max_chain, chain(r));
             for (int g = 0; g < I.rowG[r]; g++, q++) {
-                const int tp = nosort ? q : block_base(q / 64) + q % 64;
+                const int tp = nosort ? q : (row_block_base.empty() ? block_base(q / 64) : row_block_base[q / 64]) + q % 64;
                 if (g == 0) slot_of_row[r] = tp;
                 task_of_slot[tp] = Task{r, g, I.rowG[r]};
             }
