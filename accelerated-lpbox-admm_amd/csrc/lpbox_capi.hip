@@ -352,6 +352,7 @@ int finalize(lpbox_t *h) {
             std::vector<Quad> quad(Q);
             std::vector<int> quad_of_var(I.n, -1);
             auto r2 = [](int v) { return (v + 1) & ~1; };
+            std::vector<int> blk_cost(Q / QW, 0);
             for (int w = 0; w < Q / QW; w++) {
                 int A = 0, Bm = 0, Lm = 0;
                 for (int qi = 0; qi < QW; qi++) {
@@ -365,12 +366,34 @@ int finalize(lpbox_t *h) {
                     A = std::max(A, std::max(qd.tau, s1)); Bm = std::max(Bm, (qd.tail + 2) / 3); Lm = std::max(Lm, std::max(L, s1));
                     for (int t = 0; t < 4; t++) if (qd.v[t] >= 0) quad_of_var[qd.v[t]] = w * QW + qi;
                 }
-                if (r2(A) + r2(Bm) + split_bias >= r2(Lm))        // splitting does not shorten this wave's longest list
+                bool split = true;
+                if (r2(A) + r2(Bm) + split_bias >= r2(Lm)) {      // splitting does not shorten this wave's longest list
+                    split = false;
                     for (int qi = 0; qi < QW; qi++) { Quad &qd = quad[w * QW + qi]; qd.tau = clen(qd.v[0]); qd.tail = 0; }
+                }
+                blk_cost[w] = split ? (A + 3) / 4 * 4 + (Bm + 3) / 4 * 4 : (Lm + 3) / 4 * 4;
+            }
+            // multi-slot layouts: logical blocks of columns -> (wave, slot) longest-first to the least loaded wave, like the row tasks above
+            // (own list + helper list, in chunks of 4).  Unlike the rows this moves variables to other lanes, i.e. it is part of the
+            // layout the oracle mirrors through lpbox_get_layout; LPBOX_LP_SNAKECOLS=1 restores the snake deal.
+            std::vector<int> col_block_base;
+            if (h->EPT >= 2 && getenv("LPBOX_LP_SNAKECOLS") == nullptr) {
+                const int nb = Q / QW;
+                std::vector<int> border(nb);
+                for (int b2 = 0; b2 < nb; b2++) border[b2] = b2;
+                std::stable_sort(border.begin(), border.end(), [&](int a, int c) { return blk_cost[a] > blk_cost[c]; });
+                std::vector<int> load(W, 0), usedw(W, 0);
+                col_block_base.assign(nb, 0);
+                for (int b2 : border) {
+                    int best = -1;
+                    for (int w = 0; w < W; w++) if (usedw[w] < h->EPT && (best < 0 || load[w] < load[best])) best = w;
+                    col_block_base[b2] = usedw[best] * h->T + best * 64;
+                    usedw[best]++; load[best] += blk_cost[b2];
+                }
             }
             // lane of every column: bank-aware greedy as above, inside the wave's free quad slots / the quad's free lanes
             std::vector<char> used(NS, 0), slot_used(Q, 0);
-            auto qbase = [&](int w) { return block_base(w) / 4; };    // first quad slot of the 64 positions that hold logical block w
+            auto qbase = [&](int w) { return (col_block_base.empty() ? block_base(w) : col_block_base[w]) / 4; };    // first quad slot of the 64 positions that hold logical block w
             for (int qq = 0; qq < I.n; qq++) {
                 const int j = I.cperm[qq];
                 Quad &qd = quad[quad_of_var[j]];
