@@ -102,6 +102,32 @@ __device__ __forceinline__ double tm_row(const SegDev &d, int i, GET get) {
     return res;
 }
 
+// The same row product in three separable steps, for the kernels that handle the two rows of a thread TOGETHER (image problems:
+// ell_w <= 8, EPT == 2): these launches are a few microseconds long and bound by the chain of dependent memory round trips of one
+// thread, not by bandwidth -- a row at a time costs row length -> indices/values -> gathered elements -> result store, and the second
+// row's loads queue behind the first row's stores (one counter for loads and stores on this target).  ell_load can be issued before
+// the kernel's reduction of the previous launch's partials, ell_gather for both rows at once; ell_sum keeps tm_row's expression and
+// order.  Padded slots hold column i and value 0 (lpbox_seg_capi.hip), so all ell_w slots are read and the length only masks the sum.
+struct EllRow { int len; double tdi; int c[8]; double v[8]; };
+__device__ __forceinline__ void ell_load(const SegDev &d, int i, EllRow &R) {
+    R.len = d.rowlen[i];
+    R.tdi = d.td[i];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const bool in = k < d.ell_w;
+        R.c[k] = in ? d.ecol[(size_t)k * d.n + i] : i;
+        R.v[k] = in ? d.eval[(size_t)k * d.n + i] : 0.0;
+    }
+}
+__device__ __forceinline__ double ell_sum(const EllRow &R, int i, const double (&g)[8]) {
+    double tmp = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) if (k < R.len) tmp += ((R.c[k] == i) ? R.tdi : 2 * R.v[k]) * g[k];
+    double res = 0.0;
+    res += 1.0 * tmp;
+    return res;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void seg_b_init(const SegDev &d, double c1) {      // ADMM_bqp_unconstrained_init SEGcpp:658-810
     for (int s = 0; s < d.EPT; s++) {
@@ -271,6 +297,7 @@ __device__ __forceinline__ void seg_b_prep(const SegDev &d, int in, int out, int
     store_partials<1>(d, PH_A, pa, red, parity);
 }
 
+template <bool PAIR>
 __device__ __forceinline__ void seg_b_yrhs(const SegDev &d, int in, int out) {
     __shared__ double red[2 * RED_MAXV * RED_MAXW];
     int parity = 0;
@@ -291,9 +318,43 @@ __device__ __forceinline__ void seg_b_yrhs(const SegDev &d, int in, int out) {
     const int rhoUpdated = si->rhoUpdated, stale = si->dinv_stale;
     const bool refresh = si->iter != 0 && rhoUpdated;
     const double inc = (si->prev_rho1 + si->prev_rho2) * si->rcr;            // :1086
+    // two rows per thread together, their operands requested before the reduction (see ell_load)
+    const bool pair = PAIR && d.EPT == 2;
+    int ri[2] = {0, 0}; bool rok[2] = {false, false};
+    double vx[2], vz1[2], vz2[2], vtd[2], vb[2];
+    if (pair) {
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int i = blockIdx.x * (T * 2) + q * T + threadIdx.x;
+            const bool inr = i < d.n;
+            ri[q] = inr ? i : d.n - 1;
+            rok[q] = inr && d.live[ri[q]];
+            vx[q] = d.x[ri[q]]; vz1[q] = d.z1[ri[q]]; vz2[q] = d.z2[ri[q]]; vtd[q] = d.td[ri[q]]; vb[q] = d.b[ri[q]];
+        }
+    }
     double a[1];
     final_sums<1>(d, PH_A, a, red, parity);
     const double c2 = 2 * sqrt(a[0]);
+    if (pair) {
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            if (!rok[q]) continue;
+            const int i = ri[q];
+            const double x = vx[q], z1 = vz1[q], z2 = vz2[q];
+            const double t = x + z1 / rho1;
+            const double y1 = t > 1 ? 1 : (t < 0 ? 0 : t);
+            double y2 = (x + z2 / rho2) - 0.5;
+            y2 = y2 * c1 / c2 + 0.5;
+            d.y1[i] = y1; d.y2[i] = y2;
+            double td = vtd[q];
+            if (refresh) { td += inc; d.td[i] = td; }
+            if (rhoUpdated || stale) d.dinv[i] = td != 0.0 ? 1.0 / td : 1.0;    // DiagonalPreconditioner::compute (:1098-1101)
+            d.rhs[i] = (rho1 * y1 + rho2 * y2) - ((vb[q] + z1) + z2);           // :1091
+            d.x[i] = y1;                                                         // x_sol = y1 (:1104)
+        }
+        if (LEADER) { d.st[out] = *si; d.st[out].rhoUpdated = 0; d.st[out].dinv_stale = 0; }
+        return;
+    }
     for (int q = 0; q < d.EPT; q++) {
         const int i = blockIdx.x * (T * d.EPT) + q * T + threadIdx.x;
         if (i >= d.n || !d.live[i]) continue;
@@ -312,6 +373,7 @@ __device__ __forceinline__ void seg_b_yrhs(const SegDev &d, int in, int out) {
     if (LEADER) { d.st[out] = *si; d.st[out].rhoUpdated = 0; d.st[out].dinv_stale = 0; }
 }
 
+template <bool PAIR>
 __device__ __forceinline__ void seg_b_resid(const SegDev &d, int in, int out) {
     __shared__ double red[2 * RED_MAXV * RED_MAXW];
     int parity = 0;
@@ -319,6 +381,39 @@ __device__ __forceinline__ void seg_b_resid(const SegDev &d, int in, int out) {
     if (si->halt) { forward_state(d, in, out); return; }
     double pb[3] = {0.0, 0.0, 0.0};
     const double *x = d.x;
+    if (PAIR && d.EPT == 2 && d.ell_w <= 8) {            // two rows per thread together (see ell_load)
+        EllRow R[2];
+        int ri[2]; bool rok[2]; double vrhs[2], vdi[2], g[2][8];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int i = blockIdx.x * (T * 2) + q * T + threadIdx.x;
+            const bool inr = i < d.n;
+            ri[q] = inr ? i : d.n - 1;
+            ell_load(d, ri[q], R[q]);
+            rok[q] = inr && d.live[ri[q]];
+            vrhs[q] = d.rhs[ri[q]]; vdi[q] = d.dinv[ri[q]];
+        }
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+            for (int k = 0; k < 8; k++) g[q][k] = x[R[q].c[k]];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            double c0 = 0.0, c1 = 0.0, c2 = 0.0;
+            const double Mx = ell_sum(R[q], ri[q], g[q]);
+            const double rhs = vrhs[q];
+            const double r = rhs - Mx;                                        // :263
+            const double p = vdi[q] * r;                                      // :286
+            if (rok[q]) {
+                d.r[ri[q]] = r; d.p0[ri[q]] = p;
+                c0 = rhs * rhs; c1 = r * r; c2 = r * p;
+            }
+            pb[0] = pb[0] + c0; pb[1] = pb[1] + c1; pb[2] = pb[2] + c2;
+        }
+        store_partials<3>(d, PH_B, pb, red, parity);
+        if (LEADER) { d.st[out] = *si; d.st[out].pcg_k = 0; d.st[out].pcg_done = 0; d.st[out].phase = 2; }
+        return;
+    }
     for (int q = 0; q < d.EPT; q++) {
         const int i = blockIdx.x * (T * d.EPT) + q * T + threadIdx.x;
         double c0 = 0.0, c1 = 0.0, c2 = 0.0;
@@ -337,6 +432,7 @@ __device__ __forceinline__ void seg_b_resid(const SegDev &d, int in, int out) {
 }
 
 // tmp = M p with the search-direction update of the previous PCG iteration folded in
+template <bool PAIR>
 __device__ __forceinline__ void seg_b_matvec(const SegDev &d, int in, int out) {
     __shared__ double red[2 * RED_MAXV * RED_MAXW];
     int parity = 0;
@@ -347,6 +443,25 @@ __device__ __forceinline__ void seg_b_matvec(const SegDev &d, int in, int out) {
     double beta = 0.0;
     const bool first = pcg_k == 0;
     bool done = false, zero_x = false;
+    // two rows per thread, handled together (see ell_load): everything that does not depend on beta is requested before the
+    // reduction below, i.e. its latency hides behind the reduction's
+    // (single-problem launches only: they are latency-bound; a batch of problems fills the chip and wants the registers for occupancy)
+    const bool pair = PAIR && d.EPT == 2 && d.ell_w <= 8;
+    const double *pold = ((pcg_k - 1) & 1) ? d.p1 : d.p0;     // iteration k reads p_old = buffer (k-1)&1 (k >= 1), writes buffer k&1; k = 0: p0 as resid left it
+    const double *zz = d.z;
+    EllRow R[2];
+    int ri[2] = {0, 0}; bool rin[2] = {false, false}; uint8_t rlv[2] = {0, 0};
+    double rz[2] = {0.0, 0.0}, rp[2] = {0.0, 0.0};
+    if (pair) {
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int i = blockIdx.x * (T * 2) + q * T + threadIdx.x;
+            rin[q] = i < d.n; ri[q] = rin[q] ? i : d.n - 1;
+            ell_load(d, ri[q], R[q]);
+            rlv[q] = d.live[ri[q]];
+            if (first) rz[q] = d.p0[ri[q]]; else { rz[q] = zz[ri[q]]; rp[q] = pold[ri[q]]; }
+        }
+    }
     if (first) {
         double b3[3];
         final_sums<3>(d, PH_B, b3, red, parity);
@@ -375,11 +490,36 @@ __device__ __forceinline__ void seg_b_matvec(const SegDev &d, int in, int out) {
             for (int q = 0; q < d.EPT; q++) { const int i = blockIdx.x * (T * d.EPT) + q * T + threadIdx.x; if (i < d.n) d.x[i] = 0.0; }
         return;
     }
-    // p buffers: iteration k reads p_old = buffer (k-1)&1 (k >= 1) and writes buffer k&1; k = 0 uses p0 as written by resid
-    const double *pold = ((pcg_k - 1) & 1) ? d.p1 : d.p0;
     double *pnew = (pcg_k & 1) ? d.p1 : d.p0;
-    const double *zz = d.z;
     double pc[1] = {0.0};
+    if (pair) {
+        double gz[2][8], gp[2][8];
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (first) { gz[q][k] = d.p0[R[q].c[k]]; gp[q][k] = 0.0; }
+                else { gz[q][k] = zz[R[q].c[k]]; gp[q][k] = pold[R[q].c[k]]; }
+            }
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            double g[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) g[k] = first ? gz[q][k] : gz[q][k] + beta * gp[q][k];
+            const double Mp = ell_sum(R[q], ri[q], g);
+            const double pi = first ? rz[q] : rz[q] + beta * rp[q];            // p = z + beta p (:314)
+            double c = 0.0;
+            if (rin[q] && rlv[q]) {
+                const int i = ri[q];
+                if (!first) pnew[i] = pi;
+                d.tmp[i] = Mp;
+                c = pi * Mp;
+            }
+            pc[0] = pc[0] + c;
+        }
+        store_partials<1>(d, PH_C, pc, red, parity);
+        return;
+    }
     for (int q = 0; q < d.EPT; q++) {
         const int i = blockIdx.x * (T * d.EPT) + q * T + threadIdx.x;
         double c = 0.0;
@@ -402,6 +542,7 @@ __device__ __forceinline__ void seg_b_matvec(const SegDev &d, int in, int out) {
     store_partials<1>(d, PH_C, pc, red, parity);
 }
 
+template <bool PAIR>
 __device__ __forceinline__ void seg_b_update(const SegDev &d, int in, int out) {
     __shared__ double red[2 * RED_MAXV * RED_MAXW];
     int parity = 0;
@@ -409,11 +550,44 @@ __device__ __forceinline__ void seg_b_update(const SegDev &d, int in, int out) {
     if (si->halt || si->pcg_done || si->phase != 2) { forward_state(d, in, out); return; }
     const int pcg_k = si->pcg_k;
     const double absNew = si->absNew;
+    const double *p = (pcg_k & 1) ? d.p1 : d.p0;
+    // two rows per thread together: their operands are requested before the reduction that yields alpha (see ell_load)
+    const bool pair = PAIR && d.EPT == 2;
+    int ri[2] = {0, 0}; bool rok[2] = {false, false};
+    double vx[2], vr[2], vp[2], vt[2], vd[2];
+    if (pair) {
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int i = blockIdx.x * (T * 2) + q * T + threadIdx.x;
+            const bool in = i < d.n;
+            ri[q] = in ? i : d.n - 1;
+            rok[q] = in && d.live[ri[q]];
+            vx[q] = d.x[ri[q]]; vr[q] = d.r[ri[q]]; vp[q] = p[ri[q]]; vt[q] = d.tmp[ri[q]]; vd[q] = d.dinv[ri[q]];
+        }
+    }
     double c1[1];
     final_sums<1>(d, PH_C, c1, red, parity);
     const double alpha = absNew / c1[0];                                      // :295
-    const double *p = (pcg_k & 1) ? d.p1 : d.p0;
     double pd2[2] = {0.0, 0.0};
+    if (pair) {
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            double a = 0.0, b2 = 0.0;
+            double x = vx[q], r = vr[q];
+            x += alpha * vp[q];                                               // :297
+            r -= alpha * vt[q];                                               // :299
+            const double z = vd[q] * r;                                       // :309
+            if (rok[q]) {
+                const int i = ri[q];
+                d.x[i] = x; d.r[i] = r; d.z[i] = z;
+                a = r * r; b2 = r * z;
+            }
+            pd2[0] = pd2[0] + a; pd2[1] = pd2[1] + b2;
+        }
+        store_partials<2>(d, PH_D, pd2, red, parity);
+        if (LEADER) { d.st[out] = *si; d.st[out].pcg_k = pcg_k + 1; }
+        return;
+    }
     for (int q = 0; q < d.EPT; q++) {
         const int i = blockIdx.x * (T * d.EPT) + q * T + threadIdx.x;
         double a = 0.0, b2 = 0.0;
@@ -530,14 +704,14 @@ __global__ void seg_k_resume(SegDev d, int in, int out, int reset_pcg_max) { seg
 __global__ void seg_kb_resume(const SegDev *devs, int in, int out, int reset_pcg_max) { const SegDev &d = devs[blockIdx.y]; if ((int)blockIdx.x >= d.G) return; seg_b_resume(d, in, out, reset_pcg_max); }
 __global__ void __launch_bounds__(T) seg_k_prep(SegDev d, int in, int out, int do_prep) { seg_b_prep(d, in, out, do_prep); }
 __global__ void __launch_bounds__(T) seg_kb_prep(const SegDev *devs, int in, int out, int do_prep) { const SegDev &d = devs[blockIdx.y]; if ((int)blockIdx.x >= d.G) return; seg_b_prep(d, in, out, do_prep); }
-__global__ void __launch_bounds__(T) seg_k_yrhs(SegDev d, int in, int out) { seg_b_yrhs(d, in, out); }
-__global__ void __launch_bounds__(T) seg_kb_yrhs(const SegDev *devs, int in, int out) { const SegDev &d = devs[blockIdx.y]; if ((int)blockIdx.x >= d.G) return; seg_b_yrhs(d, in, out); }
-__global__ void __launch_bounds__(T) seg_k_resid(SegDev d, int in, int out) { seg_b_resid(d, in, out); }
-__global__ void __launch_bounds__(T) seg_kb_resid(const SegDev *devs, int in, int out) { const SegDev &d = devs[blockIdx.y]; if ((int)blockIdx.x >= d.G) return; seg_b_resid(d, in, out); }
-__global__ void __launch_bounds__(T) seg_k_matvec(SegDev d, int in, int out) { seg_b_matvec(d, in, out); }
-__global__ void __launch_bounds__(T) seg_kb_matvec(const SegDev *devs, int in, int out) { const SegDev &d = devs[blockIdx.y]; if ((int)blockIdx.x >= d.G) return; seg_b_matvec(d, in, out); }
-__global__ void __launch_bounds__(T) seg_k_update(SegDev d, int in, int out) { seg_b_update(d, in, out); }
-__global__ void __launch_bounds__(T) seg_kb_update(const SegDev *devs, int in, int out) { const SegDev &d = devs[blockIdx.y]; if ((int)blockIdx.x >= d.G) return; seg_b_update(d, in, out); }
+__global__ void __launch_bounds__(T) seg_k_yrhs(SegDev d, int in, int out) { seg_b_yrhs<true>(d, in, out); }
+__global__ void __launch_bounds__(T) seg_kb_yrhs(const SegDev *devs, int in, int out) { const SegDev &d = devs[blockIdx.y]; if ((int)blockIdx.x >= d.G) return; seg_b_yrhs<false>(d, in, out); }
+__global__ void __launch_bounds__(T) seg_k_resid(SegDev d, int in, int out) { seg_b_resid<true>(d, in, out); }
+__global__ void __launch_bounds__(T) seg_kb_resid(const SegDev *devs, int in, int out) { const SegDev &d = devs[blockIdx.y]; if ((int)blockIdx.x >= d.G) return; seg_b_resid<false>(d, in, out); }
+__global__ void __launch_bounds__(T) seg_k_matvec(SegDev d, int in, int out) { seg_b_matvec<true>(d, in, out); }
+__global__ void __launch_bounds__(T) seg_kb_matvec(const SegDev *devs, int in, int out) { const SegDev &d = devs[blockIdx.y]; if ((int)blockIdx.x >= d.G) return; seg_b_matvec<false>(d, in, out); }
+__global__ void __launch_bounds__(T) seg_k_update(SegDev d, int in, int out) { seg_b_update<true>(d, in, out); }
+__global__ void __launch_bounds__(T) seg_kb_update(const SegDev *devs, int in, int out) { const SegDev &d = devs[blockIdx.y]; if ((int)blockIdx.x >= d.G) return; seg_b_update<false>(d, in, out); }
 __global__ void __launch_bounds__(T) seg_k_post(SegDev d, int in, int out) { seg_b_post(d, in, out); }
 __global__ void __launch_bounds__(T) seg_kb_post(const SegDev *devs, int in, int out) { const SegDev &d = devs[blockIdx.y]; if ((int)blockIdx.x >= d.G) return; seg_b_post(d, in, out); }
 }  // namespace
