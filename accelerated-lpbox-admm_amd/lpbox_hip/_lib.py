@@ -59,6 +59,7 @@ SYMBOLS = {
     "lpbox_check_infeasible_l2f": (C.c_int, [C.c_void_p, C.c_int]),
     "lpbox_set_problem_bqp": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _ip, _ip, _dp, _dp, C.c_double, C.c_int, C.c_int]),
     "lpbox_seg_set_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "lpbox_read_jpeg_gray": (C.c_int, [C.c_char_p, C.c_void_p, C.c_long, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "lpbox_seg_legacy": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "lpbox_seg_legacy_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "lpbox_seg_get_obj": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),

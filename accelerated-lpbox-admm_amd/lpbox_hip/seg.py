@@ -1,9 +1,10 @@
 """Host-side mirror of the reference's SEGMENTATION solver interface
 (Segmentation/Segmentation/cython/src/lpbox.pyx:8-53, "SEG pyx") on top of the C-ABI (include/lpbox_hip.h).
 
-The reference's init decodes `../data/<problem>.jpg` with OpenCV (SEGcpp:690-714).  OpenCV is not available, so the JPEG is
-decoded here with PIL straight to grayscale (libjpeg's Y channel, which is what cv::imread(path, 0) asks libjpeg for); the
-resize (cv::resize INTER_LINEAR) and the cost construction (SEGcpp:46-248) run in the C-ABI library.
+The reference's init decodes `../data/<problem>.jpg` with OpenCV (SEGcpp:690-714).  OpenCV is not available; the library reads
+the JPEG itself (lpbox_read_jpeg_gray: libjpeg's Y plane with its default inverse DCT, which is what cv::imread(path, 0) asks
+libjpeg for; equal to PIL's grayscale draft bit for bit); the resize (cv::resize INTER_LINEAR) and the cost construction
+(SEGcpp:46-248) run in the C-ABI library as well.
 """
 import ctypes as C
 import os
@@ -17,8 +18,22 @@ from .lp import _as_int
 
 
 def load_gray(path):
-    """cv::imread(path, 0): 8-bit grayscale pixels, rows x cols."""
-    from PIL import Image
+    """cv::imread(path, 0): 8-bit grayscale pixels, rows x cols.  Sequential Huffman JPEGs (the reference's inputs) are read by the
+    library itself (lpbox_read_jpeg_gray: libjpeg's luminance plane, bit for bit); anything else it refuses -- a progressive JPEG, a
+    PNG -- goes through PIL when that is installed."""
+    L = _lib.load()
+    r, c = C.c_int(), C.c_int()
+    rc = L.lpbox_read_jpeg_gray(os.fsencode(path), None, 0, C.byref(r), C.byref(c))
+    if rc == 0:
+        out = np.zeros((r.value, c.value), np.uint8)
+        check(L.lpbox_read_jpeg_gray(os.fsencode(path), out.ctypes.data_as(C.c_void_p), out.size, C.byref(r), C.byref(c)), "lpbox_read_jpeg_gray")
+        return out
+    if rc == -4:                      # LPBOX_E_IO: no such file
+        check(rc, "lpbox_read_jpeg_gray")
+    try:
+        from PIL import Image
+    except ImportError:
+        check(rc, "lpbox_read_jpeg_gray")
     im = Image.open(path)
     im.draft("L", im.size)
     return np.ascontiguousarray(np.asarray(im.convert("L"), dtype=np.uint8))

@@ -157,6 +157,11 @@ int lpbox_set_problem_bqp(lpbox_t *h, int n, int nnz, const int *rowptr, const i
 /* The image part of ADMM_bqp_unconstrained_init (SEGcpp:702-756): grayscale pixels (rows x cols, row-major, what
  * cv::imread(path, 0) yields), scaled to ~num_nodes pixels (cv::resize INTER_LINEAR), costs per SEGcpp:46-248. */
 int lpbox_seg_set_image(lpbox_t *h, const unsigned char *gray, int rows, int cols, int num_nodes);
+/* `cv::imread(imagePath, 0)` (SEGcpp:705) without an image library: the luminance plane of a baseline / extended-sequential 8-bit
+ * Huffman JPEG, reconstructed with libjpeg's default ISLOW inverse DCT -- bit for bit what libjpeg yields for JCS_GRAYSCALE output,
+ * which is what OpenCV's grayscale imread and PIL's draft("L") hand out (csrc/lpbox_jpeg_host.cpp; pinned against PIL in the tests).
+ * out == NULL: only *rows / *cols.  Progressive or arithmetic-coded files: LPBOX_E_BADARG with the reason in lpbox_last_error(). */
+int lpbox_read_jpeg_gray(const char *path, unsigned char *out, long cap, int *rows, int *cols);
 /* SEG pxd:10 `int ADMM_bqp_unconstrained_legacy()` (SEGcpp:1200-1380): *energy = int(cur_obj + c). */
 int lpbox_seg_legacy(lpbox_t *h, int *energy);
 /* solve_init + solve_iter for `count` segmentation handles (each after lpbox_seg_set_image / lpbox_set_problem_bqp) advanced in lockstep by

@@ -100,6 +100,37 @@ def test_instance_comes_back_out_of_the_handle():
     assert np.array_equal(Q["colptr"], I["colptr"]) and np.array_equal(Q["rowidx"], I["rowidx"]) and np.array_equal(Q["b"], I["b"])
 
 
+def test_jpeg_reader_equals_libjpeg_luminance(tmp_path):
+    """lpbox_read_jpeg_gray against PIL's grayscale draft (= libjpeg's JCS_GRAYSCALE output, what cv::imread(path, 0) yields) on the
+    reference's sample images: every pixel equal.  Files it does not read are refused with a reason, not approximated."""
+    PIL = pytest.importorskip("PIL.Image")
+    from lpbox_hip.seg import load_gray
+    from lpbox_hip.lp import LpboxError
+    from lpbox_hip import _lib
+    import ctypes as C
+    for name in ("0.jpg", "7.jpg"):
+        path = os.path.join(GOLDEN, "seg", name)
+        im = PIL.open(path)
+        im.draft("L", im.size)
+        ref = np.asarray(im.convert("L"), dtype=np.uint8)
+        got = load_gray(path)
+        assert got.shape == ref.shape and np.array_equal(got, ref), name
+    L = _lib.load()
+    r, c = C.c_int(), C.c_int()
+    prog = str(tmp_path / "progressive.jpg")
+    PIL.fromarray(np.arange(64 * 48, dtype=np.uint8).reshape(48, 64)).save(prog, progressive=True)
+    assert L.lpbox_read_jpeg_gray(prog.encode(), None, 0, C.byref(r), C.byref(c)) == -2 and b"progressive" in L.lpbox_last_error()
+    assert np.array_equal(load_gray(prog), np.asarray(PIL.open(prog).convert("L")))          # ... and load_gray falls back to PIL for it
+    with pytest.raises(LpboxError, match="cannot open"):
+        load_gray(str(tmp_path / "missing.jpg"))
+    # a grayscale JPEG with restart markers and odd dimensions
+    odd = str(tmp_path / "odd.jpg")
+    rng = np.random.RandomState(0)
+    PIL.fromarray((rng.rand(37, 53) * 255).astype(np.uint8)).save(odd, quality=83, restart_marker_blocks=3)
+    im = PIL.open(odd)
+    assert np.array_equal(load_gray(odd), np.asarray(im.convert("L"), dtype=np.uint8))
+
+
 def test_shard_range_partitions():
     from lpbox_hip.dist import shard_range
     for total in (0, 1, 7, 256, 2048):
