@@ -14,6 +14,7 @@ from oracle import oracle as O
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CXX_DIR = os.path.join(ROOT, "accelerated-lpbox-admm_amd", "cxx", "LinearProgramming", "cython_solver")
+SEG_CXX_DIR = os.path.join(ROOT, "accelerated-lpbox-admm_amd", "cxx", "Segmentation", "cython", "src")
 
 
 def build_driver(tmp_path):
@@ -121,3 +122,35 @@ def test_cxx_driver_builds_and_fails_loudly_without_a_gpu(tmp_path):
     assert p.returncode == 1 and "no HIP device" in p.stderr
     p = subprocess.run([exe, "1", "100", "501"], env=dict(os.environ, LPBOX_DATA_ROOT=GOLDEN), capture_output=True, text=True, timeout=60)
     assert p.returncode == 1 and "cannot open" in p.stderr
+
+
+@pytest.mark.gpu
+def test_cxx_segmentation_class_equals_python_class(tmp_path):
+    """The segmentation flavour of the C++ class through `seg_solve` (= the reference's image_segmentation.cpp main): JPEG read by the
+    library, resize + costs + legacy loop on the GPU, result image written as PNG -- same energy, objective, iteration count, solution
+    and output image as the Python class on the reference's sample image, and the reference's result line in xiter_all.csv."""
+    from lpbox_hip.seg import PyLPboxADMMsolver as SegSolver
+    exe = str(tmp_path / "seg_solve")
+    subprocess.check_call(["make", "-s", "-C", SEG_CXX_DIR, "OUT=" + exe])
+    res_dir = tmp_path / "result"
+    os.makedirs(res_dir)
+    env = dict(os.environ, LPBOX_SEG_DATA_ROOT=os.path.join(GOLDEN, "seg"), LPBOX_SEG_RESULT_ROOT=str(res_dir), LPBOX_SEG_XITER_ROOT=str(tmp_path / "nox"))
+    p = subprocess.run([exe, "10000", "0", "0", "0", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    assert "Object with node is created with three inputs!" in p.stdout and "Reshaped image size: 87 X 115 = 10005" in p.stdout
+    res = dict(kv.split("=") for kv in re.search(r"^RESULT (.*)$", p.stdout, re.M).group(1).split())
+    g = SegSolver(0, 10000, 0)
+    g.data_root = os.path.join(GOLDEN, "seg")
+    g.write_files = False
+    g.solve_init()
+    energy = g.solve_iter()
+    assert int(res["energy"]) == energy and float(res["objective"]) == g.get_obj()
+    assert int(res["n"]) == g.get_org_n() == 10005 and int(res["ones"]) == int(g.get_x_sol().sum())
+    assert int(res["iterations"]) == g.counters()[0]
+    from PIL import Image
+    png = np.asarray(Image.open(res_dir / "output_0.png"))
+    ref = str(tmp_path / "ref.png")
+    g.save_img(ref)
+    assert png.dtype == np.uint8 and np.array_equal(png, np.asarray(Image.open(ref)))
+    line = open(res_dir / "xiter_all.csv").read().strip().split(",")
+    assert int(line[0]) == 0 and int(line[3]) == g.stop()[1] and abs(float(line[1]) - g.debug_scalar("cur_obj")) < 1e-5
