@@ -1158,6 +1158,9 @@ size_t lp_window_lds_bytes(int T, int NS, int LS, int ZS, int HL, int HLD) {
 bool lp_direct_supported(int T, int EPT) { return T == 512 && EPT == 1; }     // the default geometry of every n <= 512 batch
 
 // (threads, slots per thread) -> per-slot register capacities of the row-task / column gather lists.
+// (512 x 4: the load-balanced deal of lpbox_capi.hip puts each wave's longest block of row tasks / columns into slot 0, so slot 0 alone
+//  gets the longer register lists -- 12 / 12 / 8 -- and the tail path of a longer list through the LDS index arrays, two dependent LDS
+//  round trips per chunk, stays out of the PCG loop: 88.8 -> 85.1 us per iteration.  12 entries in two slots spill: 96.7 us.)
 #define LP_DISPATCH(KERNEL_CALL)                                                                                                          \
     if (T == 256 && EPT == 1) { KERNEL_CALL(256, 1, (Caps<12>), (Caps<12>), (Caps<8>)) }                                                     \
     else if (T == 256 && EPT == 2) { KERNEL_CALL(256, 2, (Caps<12, 12>), (Caps<12, 8>), (Caps<8, 4>)) }                                       \
@@ -1165,7 +1168,7 @@ bool lp_direct_supported(int T, int EPT) { return T == 512 && EPT == 1; }     //
     else if (T == 256 && EPT == 8) { KERNEL_CALL(256, 8, (Caps<8, 8, 8, 8, 8, 8, 8, 8>), (Caps<8, 8, 8, 8, 4, 4, 4, 4>), (Caps<0, 0, 0, 0, 0, 0, 0, 0>)) } \
     else if (T == 512 && EPT == 1) { KERNEL_CALL(512, 1, (Caps<12>), (Caps<12>), (Caps<8>)) }                                                \
     else if (T == 512 && EPT == 2) { KERNEL_CALL(512, 2, (Caps<12, 12>), (Caps<12, 8>), (Caps<8, 4>)) }                                      \
-    else if (T == 512 && EPT == 4) { KERNEL_CALL(512, 4, (Caps<8, 8, 8, 8>), (Caps<8, 8, 8, 8>), (Caps<4, 4, 4, 4>)) }                        \
+    else if (T == 512 && EPT == 4) { KERNEL_CALL(512, 4, (Caps<12, 8, 8, 8>), (Caps<12, 8, 8, 8>), (Caps<8, 4, 4, 4>)) }                        \
     else if (T == 1024 && EPT == 1) { KERNEL_CALL(1024, 1, (Caps<8>), (Caps<8>), (Caps<8>)) }                                                \
     else if (T == 1024 && EPT == 2) { KERNEL_CALL(1024, 2, (Caps<8, 8>), (Caps<8, 8>), (Caps<4, 4>)) }                                     \
     else return hipErrorInvalidConfiguration;
