@@ -29,6 +29,30 @@ def test_cost_builder_product_equals_oracle():
         assert np.array_equal(np.signbit(P["vals"]), np.signbit(Q["vals"]))
 
 
+def test_resize_restatement_against_an_independent_bilinear():
+    """The restated cv::resize(src, dst, Size(), s, s) INTER_LINEAR on 8-bit data (oracle = product, previous test) against torch's bilinear
+    interpolation driven with the SAME explicit scale factor -- both sample at src = (dst + 0.5) / s - 0.5 with replicated edges and no
+    antialiasing; torch in float32, OpenCV's 8-bit path through 11-bit fixed-point weights and a rounded result.  Agreement within one grey
+    level everywhere (measured: max 0.75, mean 0.26 = rounding to integers) pins the geometry of the resize -- centre convention, scale,
+    orientation -- to an independent implementation; a half-pixel shift or the size-ratio scale torch uses by default is off by up to 187
+    levels on these images.  (Output size: OpenCV rounds s * size, SEGcpp:713-714; torch floors, so the common region is compared.)  Not
+    a reference-generated vector: there is no OpenCV here, the last bit of the fixed-point path stays unpinned."""
+    import torch
+    for name in ("0.jpg", "7.jpg"):
+        g = gray(name)
+        for nodes in (10000, 2500, 40000):
+            scale = float(np.sqrt(nodes / g.size))
+            small = O.seg_resize_u8(g, scale)
+            assert small.shape == (int(round(g.shape[0] * scale)), int(round(g.shape[1] * scale)))
+            t = torch.from_numpy(g.astype(np.float32))[None, None]
+            ref = torch.nn.functional.interpolate(t, scale_factor=scale, mode="bilinear", align_corners=False, antialias=False,
+                                                  recompute_scale_factor=False)[0, 0].numpy()
+            r, c = min(ref.shape[0], small.shape[0]), min(ref.shape[1], small.shape[1])
+            assert r >= small.shape[0] - 1 and c >= small.shape[1] - 1
+            d = np.abs(small[:r, :c].astype(np.float64) - ref[:r, :c])
+            assert d.max() < 1.0 and d.mean() < 0.35, (name, nodes, d.max(), d.mean())
+
+
 def test_problem_structure_matches_survey_q3():
     """7-diagonal matrix with offsets {0, +-1, +-(ncols-1), +-ncols}, symmetric, zero row sums, integer data."""
     g = gray()
