@@ -42,7 +42,8 @@ struct BigDev {
     // row_sum_sliced) and CSC (local column -> rows), values all 1
     const int *rptr, *rcol, *cptr, *crow;
     double *x, *y1, *y2, *z1, *z2, *b, *pd, *dinv, *rhs, *r, *z, *tmp, *p0, *p1, *gsrc;   // local n-vectors
-    double *y3, *z4, *f, *fy, *Ex, *q;    // replicated l-vectors (q doubles as the all-reduce buffer of E*v)
+    double *y3, *z4, *f, *Ex, *q;         // replicated l-vectors (q doubles as the all-reduce buffer of E*v)
+    double2 *fz;                          // (f - y3, z4) per row: the two l-vectors the rhs assembly gathers, as ONE 16-byte element
     double2 *zp;                          // (z, p) of the last PCG update packed per variable: ONE 16-byte gather per entry of E*p
     double *xt;                           // PCG iterate (committed to x for the live variables after the PCG)
     uint8_t *live;                        // 1 live, 0 fixed (x holds the fixed value)

@@ -85,9 +85,9 @@ struct lpbox_big {
     int kmargin = 1;                                            // spare PCG launch groups beyond the largest count of the previous batch (LPBOX_BIG_KMARGIN)
     double kernel_ms = 0.0; long long launches = 0, collectives = 0;
     Buf<int> d_rptr, d_rcol, d_cptr, d_crow;
-    Buf<double> x, y1, y2, z1, z2, db, pd, dinv, rhs, r, z, tmp, p0, p1, gsrc, y3, z4, df, fy, Ex, q, part, red, xt, xhist, xi_out, gath, flag;
+    Buf<double> x, y1, y2, z1, z2, db, pd, dinv, rhs, r, z, tmp, p0, p1, gsrc, y3, z4, df, Ex, q, part, red, xt, xhist, xi_out, gath, flag;
     Buf<uint8_t> live, newfix;
-    Buf<double2> zp;
+    Buf<double2> zp, fz;
     Buf<int> d_live_idx;
     std::vector<int> left_idx, xi_left;   // local indices of the live variables (now / as of the last l2f window)
     long n_live_glob = 0;                 // live variables over all ranks
@@ -103,7 +103,7 @@ struct lpbox_big {
         d.x = x.p; d.y1 = y1.p; d.y2 = y2.p; d.z1 = z1.p; d.z2 = z2.p; d.b = db.p; d.pd = pd.p; d.dinv = dinv.p; d.rhs = rhs.p;
         d.r = r.p; d.z = z.p; d.tmp = tmp.p; d.p0 = p0.p; d.p1 = p1.p; d.gsrc = gsrc.p;
         d.zp = zp.p; d.xt = xt.p; d.live = live.p; d.newfix = newfix.p; d.xhist = xhist.p; d.ws_cap = ws_cap;
-        d.y3 = y3.p; d.z4 = z4.p; d.f = df.p; d.fy = fy.p; d.Ex = Ex.p; d.q = q.p; d.part = part.p; d.red = red.p; d.st = st.p;
+        d.y3 = y3.p; d.z4 = z4.p; d.f = df.p; d.fz = fz.p; d.Ex = Ex.p; d.q = q.p; d.part = part.p; d.red = red.p; d.st = st.p;
         return d;
     }
 };
@@ -257,12 +257,12 @@ void lpbox_big_destroy(lpbox_big_t *h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->d_rptr.release(); h->d_rcol.release(); h->d_cptr.release(); h->d_crow.release();
     for (Buf<double> *bp : {&h->x, &h->y1, &h->y2, &h->z1, &h->z2, &h->db, &h->pd, &h->dinv, &h->rhs, &h->r, &h->z, &h->tmp, &h->p0, &h->p1,
-                            &h->gsrc, &h->y3, &h->z4, &h->df, &h->fy, &h->Ex, &h->q, &h->part, &h->red, &h->xt, &h->xhist, &h->xi_out, &h->gath, &h->flag})
+                            &h->gsrc, &h->y3, &h->z4, &h->df, &h->Ex, &h->q, &h->part, &h->red, &h->xt, &h->xhist, &h->xi_out, &h->gath, &h->flag})
         bp->release();
     for (auto &kv : h->gexec) (void)hipGraphExecDestroy(kv.second);
     for (hipGraph_t g : h->graphs) (void)hipGraphDestroy(g);
     if (h->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(h->comm);
-    h->st.release(); h->live.release(); h->newfix.release(); h->d_live_idx.release(); h->zp.release();
+    h->st.release(); h->live.release(); h->newfix.release(); h->d_live_idx.release(); h->zp.release(); h->fz.release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -369,7 +369,8 @@ int lpbox_big_init(lpbox_big_t *h) {
             HIPCHK(bp->alloc(n));
         HIPCHK(h->live.alloc(n)); HIPCHK(h->newfix.alloc(n)); HIPCHK(h->d_live_idx.alloc(n)); HIPCHK(h->zp.alloc(n));
         HIPCHK(hipMemset(h->newfix.p, 0, (size_t)n));
-        for (Buf<double> *bp : {&h->y3, &h->z4, &h->df, &h->fy, &h->Ex}) HIPCHK(bp->alloc(l));
+        for (Buf<double> *bp : {&h->y3, &h->z4, &h->df, &h->Ex}) HIPCHK(bp->alloc(l));
+        HIPCHK(h->fz.alloc(l));
         h->q_cap = (long)h->world * (((long)l + h->world - 1) / h->world);           // whole row blocks for the exchange
         HIPCHK(h->q.alloc((size_t)h->q_cap)); HIPCHK(hipMemset(h->q.p, 0, sizeof(double) * (size_t)h->q_cap));
         if (h->comm) HIPCHK(h->gath.alloc((size_t)std::max<long>(h->q_cap, 64L * h->world)));          // W row blocks, or W scalar groups

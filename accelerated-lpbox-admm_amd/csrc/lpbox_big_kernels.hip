@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(T) big_k_init(BigDev d, double c1) {          
     if (blockIdx.x < d.G) store_partials<1>(d, pb, red, parity);
     for (int s = 0; s < d.EPTl; s++) {
         const int i = blockIdx.x * (T * d.EPTl) + s * T + threadIdx.x;
-        if (i < d.l) { d.z4[i] = 0.0; d.y3[i] = 0.0; d.fy[i] = 0.0; d.Ex[i] = 0.0; }   // :650
+        if (i < d.l) { d.z4[i] = 0.0; d.y3[i] = 0.0; d.fz[i] = make_double2(0.0, 0.0); d.Ex[i] = 0.0; }   // :650
     }
     if (LEADER) {
         BigState *s = d.st;
@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(T) big_k_prep(BigDev d, int in, int out, int d
     store_partials<1>(d, pa, red, parity);
 }
 
-// y1, y2, expression refresh (:831-866), rhs base, PCG start x0 = y1; for the rows: y3 = max(0, f - Ex - z4/rho4), fy = f - y3
+// y1, y2, expression refresh (:831-866), rhs base, PCG start x0 = y1; for the rows: y3 = max(0, f - Ex - z4/rho4), fz = (f - y3, z4)
 __global__ void __launch_bounds__(T) big_k_y(BigDev d, int in, int out) {
     const BigState *si = d.st + in;
     if (si->halt || si->phase != 1) { forward_state(d, in, out); return; }
@@ -206,9 +206,10 @@ __global__ void __launch_bounds__(T) big_k_y(BigDev d, int in, int out) {
             const int i = blockIdx.x * (T * d.EPTl) + q * T + threadIdx.x;
             if (i >= d.l) continue;
             const double f = d.f[i];
-            const double v = f - d.Ex[i] - d.z4[i] / rho4;                        // :824-828
+            const double z4 = d.z4[i];
+            const double v = f - d.Ex[i] - z4 / rho4;                             // :824-828
             const double y3 = v < 0 ? 0 : v;
-            d.y3[i] = y3; d.fy[i] = f - y3;
+            d.y3[i] = y3; d.fz[i] = make_double2(f - y3, z4);                     // what rhs_cols gathers per entry: ONE 16-byte element
         }
     if (LEADER) {
         d.st[out] = *si;
@@ -229,11 +230,10 @@ __global__ void __launch_bounds__(T) big_k_rhs_cols(BigDev d, int in, int out) {
         int k = d.cptr[j];
         for (; k + 4 <= k1; k += 4) {                      // 4 gathers in flight, additions in column order
             const int i0 = d.crow[k], i1 = d.crow[k + 1], i2 = d.crow[k + 2], i3 = d.crow[k + 3];
-            const double a0 = d.fy[i0], a1 = d.fy[i1], a2 = d.fy[i2], a3 = d.fy[i3];
-            const double b0 = d.z4[i0], b1 = d.z4[i1], b2 = d.z4[i2], b3 = d.z4[i3];
-            tA += r4Et * a0; tB += b0; tA += r4Et * a1; tB += b1; tA += r4Et * a2; tB += b2; tA += r4Et * a3; tB += b3;
+            const double2 e0 = d.fz[i0], e1 = d.fz[i1], e2 = d.fz[i2], e3 = d.fz[i3];     // (f - y3, z4) of the row
+            tA += r4Et * e0.x; tB += e0.y; tA += r4Et * e1.x; tB += e1.y; tA += r4Et * e2.x; tB += e2.y; tA += r4Et * e3.x; tB += e3.y;
         }
-        for (; k < k1; k++) { const int i = d.crow[k]; tA += r4Et * d.fy[i]; tB += d.z4[i]; }
+        for (; k < k1; k++) { const double2 e = d.fz[d.crow[k]]; tA += r4Et * e.x; tB += e.y; }
         double r_ = d.rhs[j];
         r_ += tA;
         r_ -= tB;
