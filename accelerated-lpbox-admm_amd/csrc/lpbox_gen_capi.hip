@@ -8,6 +8,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <map>
+#include <utility>
 #include <vector>
 
 #define HIPCHK(expr)                                                                                         \
@@ -74,6 +76,10 @@ struct lpbox_bqp {
     int G = 0, Gm = 0, Gl = 0, EPT = 2, EPTm = 2, EPTl = 2, kmax = 12, parity = 0;
     bool adaptive = true;
     double kernel_ms = 0.0; long long launches = 0;
+    // launch-bound inner loop: GEN_ITERS_PER_GRAPH outer iterations captured once per (PCG launch count, start parity) and replayed
+    std::map<std::pair<int, int>, hipGraphExec_t> gexec; std::vector<hipGraph_t> graphs;
+    long long graph_launches = 0;
+    bool use_graph = true;
     DevCsr dA, dCr, dCc, dEr, dEc;
     Buf<int> d_adiag;
     Buf<double> tmval, Cc_sv, Ec_sv, x, xt, y1, y2, z1, z2, db, rhs, r, z, tmp, p0, p1, gsrc, pdiag, dinv, Csq, Esq, best, dx0,
@@ -140,6 +146,35 @@ int read_state(lpbox_bqp *h) {
     HIPCHK(hipStreamSynchronize(h->stream));
     return LPBOX_OK;
 }
+// The iteration chain is a static launch sequence (device-side control state, fall-through launches), so it is replayed from a
+// hipGraph like the large-LP chain: an outer iteration flips the state ping-pong 8 + 3 kmax times, two iterations return to the
+// start parity.  Short kernels (n ~ 1e5) are launch-bound without it.
+constexpr int GEN_ITERS_PER_GRAPH = 2;
+int ensure_graph(lpbox_bqp *h, const GenDev &d, hipGraphExec_t *out) {
+    const auto key = std::make_pair(h->kmax, h->parity);
+    auto it = h->gexec.find(key);
+    if (it != h->gexec.end()) { *out = it->second; return LPBOX_OK; }
+    const int par0 = h->parity;
+    const long long l0 = h->launches;
+    hipGraph_t g = nullptr;
+    HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    int rc = LPBOX_OK;
+    for (int i = 0; i < GEN_ITERS_PER_GRAPH && rc >= 0; i++) rc = enqueue_iteration(h, d);
+    const hipError_t e2 = hipStreamEndCapture(h->stream, &g);
+    h->graph_launches = h->launches - l0;
+    h->launches = l0;
+    if (rc < 0 || e2 != hipSuccess || h->parity != par0) {
+        h->parity = par0;
+        if (g) (void)hipGraphDestroy(g);
+        return rc < 0 ? rc : lpbox_fail(LPBOX_E_HIP, "graph capture failed: %s", hipGetErrorString(e2));
+    }
+    hipGraphExec_t ex = nullptr;
+    HIPCHK(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
+    h->graphs.push_back(g);
+    h->gexec[key] = ex;
+    *out = ex;
+    return LPBOX_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -149,6 +184,7 @@ lpbox_bqp_t *lpbox_bqp_create(int device) {
     h->device = device;
     memset(&h->hst, 0, sizeof(h->hst));
     lpbox_bqp_preset(h, 0);
+    if (getenv("LPBOX_BQP_NOGRAPH")) h->use_graph = false;
     return h;
 }
 
@@ -162,6 +198,8 @@ void lpbox_bqp_destroy(lpbox_bqp_t *h) {
                             &h->Ex, &h->df, &h->part, &h->red})
         bp->release();
     h->d_adiag.release(); h->zp.release(); h->st.release();
+    for (auto &kv : h->gexec) (void)hipGraphExecDestroy(kv.second);
+    for (hipGraph_t g : h->graphs) (void)hipGraphDestroy(g);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -262,9 +300,15 @@ int lpbox_bqp_solve(lpbox_bqp_t *h, int *iterations) {                          
         if (h->hst.halt != GEN_HALT_NONE) break;
         const int remaining = h->prm.max_iters - h->hst.iter;
         if (remaining <= 0 && !h->hst.have_prev) break;
-        if (h->adaptive && h->hst.outer_total > 0) h->kmax = std::max(3, h->hst.pcg_max + 3);
+        if (h->adaptive && h->hst.outer_total > 0) h->kmax = std::max(3, h->hst.pcg_max + 1);      // one spare PCG launch group; the halt-and-resume path covers a miss
         HIPCHK(gen_launch_resume(d, 1, &h->parity, h->stream));
-        const int batch = std::min(std::max(remaining, 0), 16);
+        int batch = std::min(std::max(remaining, 0), 16);
+        if (h->use_graph && batch >= GEN_ITERS_PER_GRAPH) {
+            hipGraphExec_t ex = nullptr;
+            if (ensure_graph(h, d, &ex) < 0) { h->use_graph = false; (void)hipGetLastError(); }
+            else
+                for (; batch >= GEN_ITERS_PER_GRAPH; batch -= GEN_ITERS_PER_GRAPH) { HIPCHK(hipGraphLaunch(ex, h->stream)); h->launches += h->graph_launches; }
+        }
         for (int it = 0; it < batch; it++) CHK(enqueue_iteration(h, d));
         HIPCHK(gen_launch_prep(d, 0, &h->parity, h->stream)); h->launches++;          // finalise the last iteration of the batch
     }
