@@ -82,21 +82,23 @@ const int kZigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5,
 constexpr int CB = 13, P1 = 2;
 constexpr int32_t F0298 = 2446, F0390 = 3196, F0541 = 4433, F0765 = 6270, F0899 = 7373, F1175 = 9633, F1501 = 12299, F1847 = 15137,
                   F1961 = 16069, F2053 = 16819, F2562 = 20995, F3072 = 25172;
-inline int32_t descale(int32_t x, int n) { return (x + (1 << (n - 1))) >> n; }
+// (64-bit temporaries: identical values for every legal coefficient block -- IJG's INT32 arithmetic does not overflow on those -- and no
+//  signed overflow on a corrupt file, whose coefficients are clamped to +-2^20 before they get here)
+inline int64_t descale(int64_t x, int n) { return (x + ((int64_t)1 << (n - 1))) >> n; }
 
-inline void idct_1d(const int32_t in[8], int32_t out[8], int shift) {
-    int32_t z2 = in[2], z3 = in[6];
-    int32_t z1 = (z2 + z3) * F0541;
-    int32_t tmp2 = z1 + z3 * (-F1847);
-    int32_t tmp3 = z1 + z2 * F0765;
+inline void idct_1d(const int64_t in[8], int64_t out[8], int shift) {
+    int64_t z2 = in[2], z3 = in[6];
+    int64_t z1 = (z2 + z3) * F0541;
+    int64_t tmp2 = z1 + z3 * (-F1847);
+    int64_t tmp3 = z1 + z2 * F0765;
     z2 = in[0]; z3 = in[4];
-    int32_t tmp0 = (z2 + z3) * (1 << CB);
-    int32_t tmp1 = (z2 - z3) * (1 << CB);
-    const int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    int64_t tmp0 = (z2 + z3) * (1 << CB);
+    int64_t tmp1 = (z2 - z3) * (1 << CB);
+    const int64_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
     tmp0 = in[7]; tmp1 = in[5]; tmp2 = in[3]; tmp3 = in[1];
     z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
-    int32_t z4 = tmp1 + tmp3;
-    const int32_t z5 = (z3 + z4) * F1175;
+    int64_t z4 = tmp1 + tmp3;
+    const int64_t z5 = (z3 + z4) * F1175;
     tmp0 *= F0298; tmp1 *= F2053; tmp2 *= F3072; tmp3 *= F1501;
     z1 *= -F0899; z2 *= -F2562; z3 *= -F1961; z4 *= -F0390;
     z3 += z5; z4 += z5;
@@ -108,21 +110,23 @@ inline void idct_1d(const int32_t in[8], int32_t out[8], int shift) {
 }
 
 inline void idct_islow(const int32_t coef[64], uint8_t *dst, long stride) {
-    int32_t ws[64];
+    int64_t ws[64];
     for (int c = 0; c < 8; c++) {                                   // pass 1: columns
-        int32_t in[8], out[8];
+        int64_t in[8], out[8];
         bool ac = false;
         for (int r = 0; r < 8; r++) { in[r] = coef[r * 8 + c]; if (r && in[r]) ac = true; }
-        if (!ac) { const int32_t dc = in[0] * (1 << P1); for (int r = 0; r < 8; r++) ws[r * 8 + c] = dc; continue; }
+        if (!ac) { const int64_t dc = in[0] * (1 << P1); for (int r = 0; r < 8; r++) ws[r * 8 + c] = dc; continue; }
         idct_1d(in, out, CB - P1);
         for (int r = 0; r < 8; r++) ws[r * 8 + c] = out[r];
     }
     for (int r = 0; r < 8; r++) {                                   // pass 2: rows, descale by 2^(CONST_BITS + PASS1_BITS + 3), centre, clamp
-        int32_t out[8];
+        int64_t out[8];
         idct_1d(ws + r * 8, out, CB + P1 + 3);
-        for (int c = 0; c < 8; c++) { int v = out[c] + 128; dst[r * stride + c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+        for (int c = 0; c < 8; c++) { const int64_t v = out[c] + 128; dst[r * stride + c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
     }
 }
+
+inline int32_t clamp20(int64_t v) { return (int32_t)(v < -(1 << 20) ? -(1 << 20) : (v > (1 << 20) ? (1 << 20) : v)); }   // never binds on a legal stream
 
 int fail_jpeg(const char *path, const char *what) { return lpbox_fail(LPBOX_E_BADARG, "%s: %s", path, what); }
 
@@ -184,6 +188,7 @@ extern "C" int lpbox_read_jpeg_gray(const char *path, unsigned char *out, long c
             H = (s[1] << 8) | s[2]; W = (s[3] << 8) | s[4];
             const int nc = s[5];
             if (H <= 0 || W <= 0 || nc < 1 || nc > 4 || sl < 6 + 3 * (size_t)nc) return fail_jpeg(path, "bad SOF");
+            if ((long)H * W > (1L << 26)) return fail_jpeg(path, "image larger than 64 Mpixel");
             comps.resize(nc);
             for (int c = 0; c < nc; c++) {
                 comps[c].id = s[6 + 3 * c]; comps[c].h = s[7 + 3 * c] >> 4; comps[c].v = s[7 + 3 * c] & 15; comps[c].tq = s[8 + 3 * c] & 3;
@@ -235,8 +240,8 @@ extern "C" int lpbox_read_jpeg_gray(const char *path, unsigned char *out, long c
                                 int32_t coef[64] = {0};
                                 const int t = decode_sym(r, dc[c.td]);
                                 if (t < 0 || t > 11) return fail_jpeg(path, "corrupt DC code");
-                                c.pred += extend(r.receive(t), t);
-                                coef[0] = c.pred * (int32_t)Q[c.tq][0];
+                                c.pred = clamp20((int64_t)c.pred + extend(r.receive(t), t));
+                                coef[0] = clamp20((int64_t)c.pred * Q[c.tq][0]);
                                 for (int k = 1; k < 64;) {
                                     const int rs = decode_sym(r, ac[c.ta]);
                                     if (rs < 0) return fail_jpeg(path, "corrupt AC code");
@@ -244,7 +249,7 @@ extern "C" int lpbox_read_jpeg_gray(const char *path, unsigned char *out, long c
                                     if (sz == 0) { if (run == 15) { k += 16; continue; } break; }      // ZRL / EOB
                                     k += run;
                                     if (k > 63) return fail_jpeg(path, "corrupt AC run");
-                                    coef[kZigzag[k]] = extend(r.receive(sz), sz) * (int32_t)Q[c.tq][k];
+                                    coef[kZigzag[k]] = clamp20((int64_t)extend(r.receive(sz), sz) * Q[c.tq][k]);
                                     k++;
                                 }
                                 if (ci == 0) idct_islow(coef, &plane[((size_t)(my * c.v + by) * 8) * pw + (size_t)(mx * c.h + bx) * 8], pw);
