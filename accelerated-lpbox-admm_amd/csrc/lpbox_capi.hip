@@ -127,7 +127,7 @@ struct lpbox_solver {
         d.rs_ptr = rs_ptr.p; d.rs_col = rs_col.p; d.cs_ptr = cs_ptr.p; d.cs_row = cs_row.p; d.hs_ptr = hs_ptr.p; d.cmeta = cmeta.p; d.rid = rid.p; d.rmeta = rmeta.p; d.rgl = rgl.p;
         d.x = x.p; d.z1 = z1.p; d.z2 = z2.p; d.b = b.p; d.pd = pd.p; d.live = live.p; d.newfix = newfix.p;
         d.z4 = z4.p; d.f = f.p; d.dsc = dsc.p; d.isc = isc.p; d.hist = hist.p;
-        d.ctl = ctl.p; d.dctl = dctl.p; d.xhist = xhist.p; d.ws_cap = ws_cap; d.stamps = stamps.p;
+        d.ctl = ctl.p; d.dctl = dctl.p; d.xhist = xhist.p; d.ws_cap = ws_cap; d.stamps = stamps.p; d.stamp_wave = getenv("LPBOX_STAMP_WAVE") ? atoi(getenv("LPBOX_STAMP_WAVE")) : 0;
         d.H = direct ? Hinv.p : nullptr; d.HL = direct ? HL : 0; d.HLD = direct ? HLD : 0; d.rdir = rdir.p; d.dng = dng.p;
         return d;
     }

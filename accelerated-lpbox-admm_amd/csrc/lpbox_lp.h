@@ -71,6 +71,7 @@ struct LpBatchDev {
     const int16_t *rdir;          // row-task slot -> dense index of its row among the G rows, -1 = D row
     const int *dng;               // G rows per instance
     unsigned long long *stamps;   // diagnostic build only (LPBOX_STAMPS): 16 phase counters per instance, else nullptr
+    int stamp_wave;               // ... of this wavefront of the workgroup (LPBOX_STAMP_WAVE, default 0)
 };
 
 // launchers (lpbox_lp_kernels.hip)

@@ -35,7 +35,7 @@ namespace {
 #define STAMP_DECL unsigned long long st_acc[16] = {0}; unsigned long long st_t = __builtin_amdgcn_s_memtime();
 #define STAMP(k) { __builtin_amdgcn_sched_barrier(0); unsigned long long st_n = __builtin_amdgcn_s_memtime(); \
                    __builtin_amdgcn_s_waitcnt(0xC07F); st_acc[k] += st_n - st_t; st_t = st_n; __builtin_amdgcn_sched_barrier(0); }
-#define STAMP_STORE if (tid == 0 && bd.stamps) { for (int k = 0; k < 16; k++) bd.stamps[(size_t)inst * 16 + k] = st_acc[k]; }
+#define STAMP_STORE if (tid == 64 * bd.stamp_wave && bd.stamps) { for (int k = 0; k < 16; k++) bd.stamps[(size_t)inst * 16 + k] = st_acc[k]; }
 #else
 #define STAMP_DECL
 #define STAMP(k)
