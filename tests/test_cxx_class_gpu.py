@@ -69,6 +69,35 @@ def test_cxx_driver_equals_python_class_and_oracle(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cxx_side_effect_files_equal_python(tmp_path):
+    """print_info = 2 (LPcpp:776-783, :903-909, :1081): the C++ class writes <root>/xiter/<k>_<j>_xiters_<i>.csv and appends to allres.csv
+    like the Python wrapper, whose formats are pinned to the reference's own readers (tests/test_trainer_pins.py): same bytes."""
+    import shutil
+    from lpbox_hip.lp import PyLPboxADMMsolver
+    exe = build_driver(tmp_path)
+    roots = []
+    for name in ("cxx", "py"):
+        root = tmp_path / name
+        os.makedirs(root / "instance" / "100_500")
+        os.makedirs(root / "xiter")
+        for f in ("instance_1_C.txt", "instance_1_b.txt"):
+            shutil.copy(os.path.join(GOLDEN, "instance", "100_500", f), root / "instance" / "100_500" / f)
+        roots.append(root)
+    run_driver(exe, roots[0], 1, 100, 500, 300, 0, 2)
+    g = PyLPboxADMMsolver(2)
+    g.data_root = str(roots[1])
+    g.read_File(1, 100, 500)
+    g.solve_init()
+    g.solve_iter(0, 300)
+    a = open(roots[0] / "xiter" / "100_500_xiters_1.csv").read()
+    b = open(roots[1] / "xiter" / "100_500_xiters_1.csv").read()
+    assert a == b and a.count("\n") == 300 and a.startswith("Iter1,")
+    la = open(roots[0] / "xiter" / "allres.csv").read().strip().split(",")
+    lb = open(roots[1] / "xiter" / "allres.csv").read().strip().split(",")
+    assert la[:3] == lb[:3] and len(la) == 4                       # instance, -objective, iterations (the fourth field is the wall-clock)
+
+
+@pytest.mark.gpu
 def test_cxx_rule_based_fixing_equals_python(tmp_path):
     """ADMM_lp_iters_fix through the C++ class (LPcpp:1689-2286, repaired semantics of DESIGN.md section 16) takes the decisions of
     PyLPboxADMMsolver.solve_iter_fix, which tests/test_lp_fix_rule_gpu.py holds against the oracle: same fixes, same end state."""
