@@ -605,6 +605,7 @@ __device__ __forceinline__ void seg_b_update(const SegDev &d, int in, int out) {
     if (LEADER) { d.st[out] = *si; d.st[out].pcg_k = pcg_k + 1; }
 }
 
+template <bool PAIR>
 __device__ __forceinline__ void seg_b_post(const SegDev &d, int in, int out) {
     __shared__ double red[2 * RED_MAXV * RED_MAXW];
     int parity = 0;
@@ -612,6 +613,22 @@ __device__ __forceinline__ void seg_b_post(const SegDev &d, int in, int out) {
     if (si->halt || si->phase != 2) { forward_state(d, in, out); return; }
     const int pcg_k = si->pcg_k, rec = si->rec, cc = si->cc;
     int done = si->pcg_done;
+    // two rows per thread together, operands requested before the pending reduction (see ell_load)
+    const bool pair = PAIR && d.EPT == 2 && d.ell_w <= 8;
+    EllRow R[2];
+    int ri[2] = {0, 0}; bool rok[2] = {false, false};
+    double vx[2], vy1[2], vy2[2], vb[2], vz1[2], vz2[2];
+    if (pair) {
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int i = blockIdx.x * (T * 2) + q * T + threadIdx.x;
+            const bool inr = i < d.n;
+            ri[q] = inr ? i : d.n - 1;
+            ell_load(d, ri[q], R[q]);
+            rok[q] = inr && d.live[ri[q]];
+            vx[q] = d.x[ri[q]]; vy1[q] = d.y1[ri[q]]; vy2[q] = d.y2[ri[q]]; vb[q] = d.b[ri[q]]; vz1[q] = d.z1[ri[q]]; vz2[q] = d.z2[ri[q]];
+        }
+    }
     if (!done) {                           // the exit test of the last update is still pending
         double d2[2];
         final_sums<2>(d, PH_D, d2, red, parity);
@@ -624,6 +641,36 @@ __device__ __forceinline__ void seg_b_post(const SegDev &d, int in, int out) {
     const double *x = d.x;
     double e5[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, e2[3] = {0.0, 0.0, 0.0};
     double *xh = (rec && cc < d.ws_cap) ? d.xhist + (size_t)cc * d.n : nullptr;
+    if (pair) {
+        double xc[2][8];
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+            for (int k = 0; k < 8; k++) xc[q][k] = x[R[q].c[k]];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0, v4 = 0.0, v5 = 0.0, v6 = 0.0, v7 = 0.0;
+            if (rok[q]) {
+                const int i = ri[q];
+                const double xi = vx[q], y1 = vy1[q], y2 = vy2[q], bi = vb[q];
+                d.z1[i] = vz1[q] + g1 * (xi - y1);                                // :1119-1120
+                const double z2n = vz2[q] + g2 * (xi - y2);
+                d.z2[i] = z2n;
+                { const double u = (xi + z2n / rho2n) - 0.5; v7 = u * u; }
+                if (xh) xh[i] = xi;
+                double t1 = 0, t2 = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) if (k < R[q].len) { t1 += R[q].v[k] * xc[q][k]; t2 += R[q].v[k] * (xc[q][k] >= 0.5 ? 1.0 : 0.0); }
+                double Ax = 0.0; Ax += 1.0 * t1;
+                double Axb = 0.0; Axb += 1.0 * t2;
+                const double xb = xi >= 0.5 ? 1.0 : 0.0;
+                const double d1 = xi - y1, d2 = xi - y2;
+                v0 = xi * xi; v1 = d1 * d1; v2 = d2 * d2; v3 = xi * Ax; v4 = bi * xi; v5 = xb * Axb; v6 = bi * xb;
+            }
+            e5[0] = e5[0] + v0; e5[1] = e5[1] + v1; e5[2] = e5[2] + v2; e5[3] = e5[3] + v3; e5[4] = e5[4] + v4;
+            e2[0] = e2[0] + v5; e2[1] = e2[1] + v6; e2[2] = e2[2] + v7;
+        }
+    } else
     for (int q = 0; q < d.EPT; q++) {
         const int i = blockIdx.x * (T * d.EPT) + q * T + threadIdx.x;
         double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0, v4 = 0.0, v5 = 0.0, v6 = 0.0, v7 = 0.0;
@@ -712,8 +759,8 @@ __global__ void __launch_bounds__(T) seg_k_matvec(SegDev d, int in, int out) { s
 __global__ void __launch_bounds__(T) seg_kb_matvec(const SegDev *devs, int in, int out) { const SegDev &d = devs[blockIdx.y]; if ((int)blockIdx.x >= d.G) return; seg_b_matvec<false>(d, in, out); }
 __global__ void __launch_bounds__(T) seg_k_update(SegDev d, int in, int out) { seg_b_update<true>(d, in, out); }
 __global__ void __launch_bounds__(T) seg_kb_update(const SegDev *devs, int in, int out) { const SegDev &d = devs[blockIdx.y]; if ((int)blockIdx.x >= d.G) return; seg_b_update<false>(d, in, out); }
-__global__ void __launch_bounds__(T) seg_k_post(SegDev d, int in, int out) { seg_b_post(d, in, out); }
-__global__ void __launch_bounds__(T) seg_kb_post(const SegDev *devs, int in, int out) { const SegDev &d = devs[blockIdx.y]; if ((int)blockIdx.x >= d.G) return; seg_b_post(d, in, out); }
+__global__ void __launch_bounds__(T) seg_k_post(SegDev d, int in, int out) { seg_b_post<true>(d, in, out); }
+__global__ void __launch_bounds__(T) seg_kb_post(const SegDev *devs, int in, int out) { const SegDev &d = devs[blockIdx.y]; if ((int)blockIdx.x >= d.G) return; seg_b_post<false>(d, in, out); }
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------------
