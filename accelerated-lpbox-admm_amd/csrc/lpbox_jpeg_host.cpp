@@ -215,8 +215,14 @@ extern "C" int lpbox_read_jpeg_gray(const char *path, unsigned char *out, long c
             if (cols) *cols = W;
             if (!out) return LPBOX_OK;                              // size query
             if (cap < (long)H * W) return lpbox_fail(LPBOX_E_BADARG, "buffer too small for a %d x %d image", H, W);
+            // T.81 A.2.2 / libjpeg (comps_in_scan == 1): the MCU of a one-component scan is ONE 8x8 block in raster order,
+            // whatever sampling factors the frame header states
+            if (comps.size() == 1) comps[0].h = comps[0].v = 1;
             int hmax = 1, vmax = 1;
             for (auto &c : comps) { hmax = c.h > hmax ? c.h : hmax; vmax = c.v > vmax ? c.v : vmax; }
+            // libjpeg would upsample a luminance plane that is not the most finely sampled component; no encoder in use writes
+            // such files, so they are refused rather than approximated (the plane below is sized from component 0)
+            if (comps[0].h != hmax || comps[0].v != vmax) return fail_jpeg(path, "luminance is subsampled: not supported");
             const int mcux = (W + 8 * hmax - 1) / (8 * hmax), mcuy = (H + 8 * vmax - 1) / (8 * vmax);
             const Comp &Y = comps[0];
             const long pw = (long)mcux * Y.h * 8, ph = (long)mcuy * Y.v * 8;       // padded luminance plane
@@ -256,6 +262,7 @@ extern "C" int lpbox_read_jpeg_gray(const char *path, unsigned char *out, long c
                             }
                     }
                 }
+            if (pw < W || ph < H) return fail_jpeg(path, "internal: luminance plane smaller than the image");
             for (int y = 0; y < H; y++) memcpy(out + (size_t)y * W, &plane[(size_t)y * pw], (size_t)W);
             return LPBOX_OK;
         }

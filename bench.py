@@ -13,8 +13,13 @@ executed by all ranks / time; ms_per_step = wall-clock to converge.  With --gpus
 relabelled by a rank-seeded permutation (isomorphic problems, different arithmetic trajectories and iteration counts).
 Config 3: step = one ADMM_bqp_unconstrained_legacy solve; config 5: step = init + 100 ADMM iterations of the sharded instance.
 
-Launch:  python bench.py [--config C] [--gpus 1] [--steps K] [--warmup W]
+Launch:  python bench.py [--config C] [--gpus N] [--steps K] [--warmup W]
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+With --gpus N > 1 and no WORLD_SIZE in the environment bench.py starts its N ranks itself: N fresh child processes (one per GPU,
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set), started BEFORE the parent has made any GPU call; the parent only relays rank 0's line.
+
+Without --config (what the driver runs) the headline line is config 2 and, on one GPU, short passes of configs 4, 3 and 5 follow
+OUTSIDE the headline's timed region; each lands under detail.configs.<c> as a complete line of its own (value, roofline, cpu_baseline).
 """
 import argparse
 import glob
@@ -108,11 +113,36 @@ def _eigen_solve(I, log=None):
     return -s.cal_Obj(), s.total_outer_iters
 
 
-def cpu_baseline_lp(insts, sample, pool_count, workers):
-    """The CPU oracle (a port: the reference's Eigen path cannot be built here) in Eigen's reduction order, logging off:
-    (i) 1 thread on a bounded sample, (ii) `workers` single-thread processes over `pool_count` instances.
-    Runs BEFORE the GPU is initialised (the pool forks)."""
+def usable_cpus():
+    """CPUs this process may really use: the affinity mask, capped by a cgroup-v2 CPU quota if one is set."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def _pool_pass(insts, count, workers):
+    """`count` solves (the batch cyclically) by `workers` single-thread processes, one instance per process at a time."""
     from concurrent.futures import ProcessPoolExecutor
+    tasks = [insts[i % len(insts)] for i in range(count)]
+    t0 = time.perf_counter()
+    with ProcessPoolExecutor(workers) as ex:
+        res = list(ex.map(_eigen_solve, tasks, chunksize=1))
+    return res, time.perf_counter() - t0
+
+
+def cpu_baseline_lp(insts, sample, pool_count, with_log=True):
+    """The CPU oracle (a port: the reference's Eigen path cannot be built here) in Eigen's reduction order, logging off:
+    (i) 1 thread on a bounded sample, (ii) one single-thread process per usable host core (`nproc` processes) over
+    `pool_count` solves, (iii) the same with 16 processes (the figure rounds 1-2 reported as "all cores").
+    Runs BEFORE the GPU is initialised (the pools fork)."""
     from oracle import oracle as O
     O.build()
     model, cc = host_info()
@@ -120,29 +150,48 @@ def cpu_baseline_lp(insts, sample, pool_count, workers):
     one = [_eigen_solve(I) for I in insts[:sample]]
     dt1 = time.perf_counter() - t0
     it1 = sum(r[1] for r in one)
+    ncpu = usable_cpus()
+    host = os.cpu_count() or ncpu
+    quota = (f"this job may use {ncpu} of the host's {host} hardware threads (affinity mask / cgroup cpu.max quota)" if ncpu < host
+             else f"all {host} hardware threads of the host are usable")
     out = dict(value=it1 / dt1, unit="instance-iterations/s", cores=1, kind="port",
                sample=f"first {sample} instances of the batch solved to convergence by oracle/lpbox_oracle.c (Eigen reduction order, "
-                      f"logging off), {it1} iterations in {dt1:.1f} s", cpu_model=model, compiler=cc, host_cores=os.cpu_count())
+                      f"logging off), {it1} iterations in {dt1:.1f} s", cpu_model=model, compiler=cc, host_cores=host,
+               usable_cores=ncpu, cpu_quota=quota)
     res = one
-    if pool_count > sample and workers > 1:
-        t0 = time.perf_counter()
-        with ProcessPoolExecutor(workers) as ex:
-            res = list(ex.map(_eigen_solve, insts[:pool_count], chunksize=1))
-        dtp = time.perf_counter() - t0
-        out["all_cores"] = dict(value=sum(r[1] for r in res) / dtp, unit="instance-iterations/s", processes=workers,
-                                sample=f"first {pool_count} instances, one single-thread process per instance at a time, {dtp:.1f} s")
-    # footnote: what ./test really does -- the reference's per-iteration text log is on by default (LPh:148, LPcpp:1013-1067)
-    import tempfile
-    k = max(1, min(sample, 8))
-    with tempfile.TemporaryDirectory() as td:
-        t0 = time.perf_counter()
-        itl = sum(_eigen_solve(I, os.path.join(td, "log_%d.txt" % j))[1] for j, I in enumerate(insts[:k]))
-        dtl = time.perf_counter() - t0
-    out["with_reference_default_log"] = dict(value=itl / dtl, unit="instance-iterations/s", cores=1,
-                                             sample=f"first {k} instances again with the per-iteration log (7 norms, 12 lines per iteration) "
-                                                    f"appended to a temporary file, {dtl:.1f} s")
+    if pool_count > sample and ncpu > 1:
+        # enough solves that the tail (the slowest instance of the batch runs 1.5 x the mean) does not dominate a wide pool
+        count = max(pool_count, 4 * ncpu) if ncpu > 64 else pool_count
+        res, dtp = _pool_pass(insts, count, ncpu)
+        out["all_cores"] = dict(value=sum(r[1] for r in res) / dtp, unit="instance-iterations/s", cores=ncpu, processes=ncpu,
+                                sample=f"{count} solves (the batch's first {min(count, len(insts))} instances"
+                                       + (", cyclically" if count > len(insts) else "") + f") by {ncpu} single-thread processes = one "
+                                       f"per usable host core ({quota}), one instance per process at a time, {dtp:.1f} s")
+        if ncpu < host:
+            # SURVEY 8d(ii) asks for nproc processes; under a CPU quota more processes only time-share the same cores.  The
+            # whole-host figure can therefore only be extrapolated -- an upper bound: SMT siblings and memory do not scale linearly
+            out["all_cores"]["extrapolated_to_host_cores"] = dict(
+                value=out["all_cores"]["value"] * host / ncpu, cores=host,
+                note=f"NOT measured: the {ncpu}-core figure x {host}/{ncpu}, linear-scaling upper bound for the whole host")
+        if ncpu > 16:
+            r16, dt16 = _pool_pass(insts, min(pool_count, 64), 16)
+            out["processes_16"] = dict(value=sum(r[1] for r in r16) / dt16, unit="instance-iterations/s", cores=16, processes=16,
+                                       sample=f"first {len(r16)} instances by 16 single-thread processes, {dt16:.1f} s "
+                                              "(what rounds 1-2 printed under the name all_cores)")
+    if with_log:
+        # footnote: what ./test really does -- the reference's per-iteration text log is on by default (LPh:148, LPcpp:1013-1067)
+        import tempfile
+        k = max(1, min(sample, 8))
+        with tempfile.TemporaryDirectory() as td:
+            t0 = time.perf_counter()
+            itl = sum(_eigen_solve(I, os.path.join(td, "log_%d.txt" % j))[1] for j, I in enumerate(insts[:k]))
+            dtl = time.perf_counter() - t0
+        out["with_reference_default_log"] = dict(value=itl / dtl, unit="instance-iterations/s", cores=1,
+                                                 sample=f"first {k} instances again with the per-iteration log (7 norms, 12 lines per iteration) "
+                                                        f"appended to a temporary file, {dtl:.1f} s")
     out["note"] = "value / all_cores: logging off, as in every solver object this repository creates"
-    return out, np.array([r[0] for r in res]), np.array([r[1] for r in res])
+    k = min(len(res), len(insts))
+    return out, np.array([r[0] for r in res[:k]]), np.array([r[1] for r in res[:k]])
 
 
 def pmc_traffic(kernel_tag, instances):
@@ -162,57 +211,129 @@ def dist_setup(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     return rank, local_rank, world
 
 
-def main():
+def self_launch(args, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes.  This parent has not touched the GPU
+    (no HIP call, no torch import) and never will; it waits for the ranks, relays rank 0's JSON line and returns the worst exit code."""
+    import socket
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4, 5))
+    ap.add_argument("--config", type=int, default=None, choices=(2, 3, 4, 5),
+                    help="default: config 2 as the headline + short passes of 4, 3, 5 under detail.configs (one GPU)")
     ap.add_argument("--batch", type=int, default=256, help="instances per GPU (configs 2 and 4)")
     ap.add_argument("--cpu-sample", type=int, default=None, help="instances solved by ONE CPU thread for cpu_baseline (0 = skip)")
     ap.add_argument("--cpu-pool", type=int, default=None, help="instances solved by the all-cores CPU pass")
     ap.add_argument("--variables", type=float, default=1e6, help="variables of the config 5 instance")
-    args = ap.parse_args()
+    ap.add_argument("--no-extra-configs", action="store_true", help="default run: headline only, no detail.configs")
+    args = ap.parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args, argv)
     rank, local_rank, world = dist_setup(args)
-    if args.steps is None:
-        args.steps = {2: 5, 4: 2, 3: 5, 5: 3}[args.config]
-    if args.config in (2, 4):
-        run_lp_batch(args, rank, local_rank, world)
-    elif args.config == 3:
-        run_seg(args, rank, local_rank, world)
-    else:
-        run_big(args, rank, local_rank, world)
+    headline = args.config or 2
+    extras = [] if (args.config is not None or world > 1 or args.no_extra_configs or STUB) else [4, 3, 5]
+
+    def args_for(c, nested):
+        a = argparse.Namespace(**vars(args))
+        a.config = c
+        if nested or a.steps is None:
+            a.steps = {2: 5, 4: 2, 3: 5, 5: 3}[c] if not nested else {4: 2, 3: 3, 5: 2}[c]
+        if nested:
+            a.warmup = 1
+        return a
+
+    # CPU legs of the LP configs first: their process pools fork, which must happen before this process initialises the GPU
+    cpu = {}
+    if world == 1 and rank == 0:
+        for c in [headline] + extras:
+            if c in (2, 4):
+                cpu[c] = cpu_leg_lp(args_for(c, c != headline), nested=c != headline)
+    ctx = gpu_dist_init(rank, local_rank, world)
+    line = RUN[headline](args_for(headline, False), ctx, cpu.get(headline))
+    if rank == 0 and extras:
+        line["detail"]["configs"] = {}
+        for c in extras:
+            try:
+                sub = RUN[c](args_for(c, True), ctx, cpu.get(c))
+            except Exception as e:                      # the headline stands; say what failed
+                sub = {"error": f"{type(e).__name__}: {e}"}
+            line["detail"]["configs"][str(c)] = sub
+        line["detail"]["configs"]["note"] = ("BASELINE configs[3], [2], [4] measured in this same run AFTER the headline's timed region: "
+                                             "each entry is a complete bench line of its own (python bench.py --config C prints it alone)")
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    finish(world)
+    return 0
 
 
-def gpu_dist_init(local_rank, world):
-    import torch
-    import torch.distributed as dist
-    from lpbox_hip import _lib
-    L = _lib.load()
-    if L.lpbox_device_count() < 1:
-        raise SystemExit("bench.py: no HIP device visible; the HIP path has no CPU fallback")
+STUB = os.environ.get("LPBOX_BENCH_STUB", "") not in ("", "0")      # tests only: no GPU, tests/bench_stub.py in place of LpBatch
+
+
+class Ctx:
+    pass
+
+
+def gpu_dist_init(rank, local_rank, world):
+    ctx = Ctx()
+    ctx.rank, ctx.world = rank, world
     # rehearsal on a one-GPU box only: LPBOX_BENCH_BACKEND=gloo LPBOX_BENCH_DEVICE=0 puts every rank on one card
     backend = os.environ.get("LPBOX_BENCH_BACKEND", "nccl")
-    if "LPBOX_BENCH_DEVICE" in os.environ:
-        local_rank = int(os.environ["LPBOX_BENCH_DEVICE"])
-    torch.cuda.set_device(local_rank)
-    if world > 1:
+    if STUB:
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
+            raise SystemExit("LPBOX_BENCH_STUB needs LPBOX_BENCH_BACKEND=gloo")
+        import torch.distributed as dist
+        import torch
+        if world > 1:
             dist.init_process_group(backend)
+        gpu_sync = lambda: None
+    else:
+        import torch
+        import torch.distributed as dist
+        from lpbox_hip import _lib
+        L = _lib.load()
+        if L.lpbox_device_count() < 1:
+            raise SystemExit("bench.py: no HIP device visible; the HIP path has no CPU fallback")
+        if "LPBOX_BENCH_DEVICE" in os.environ:
+            local_rank = int(os.environ["LPBOX_BENCH_DEVICE"])
+        torch.cuda.set_device(local_rank)
+        if world > 1:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(backend)
+        gpu_sync = torch.cuda.synchronize
     red_dev = "cuda" if backend == "nccl" else "cpu"
 
     def sync():
-        torch.cuda.synchronize()
+        gpu_sync()
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize()
+            gpu_sync()
 
     def allred(v, op):
         if world == 1:
@@ -221,7 +342,8 @@ def gpu_dist_init(local_rank, world):
         dist.all_reduce(t, op=getattr(dist.ReduceOp, op))
         return float(t.item())
 
-    return local_rank, sync, allred, backend
+    ctx.local_rank, ctx.sync, ctx.allred, ctx.backend = local_rank, sync, allred, backend
+    return ctx
 
 
 def finish(world):
@@ -233,21 +355,37 @@ def finish(world):
 # ------------------------------------------------------------------------------------------------------------------------
 # configs 2 and 4: batches of independent LP instances on the persistent one-workgroup-per-instance kernel
 # ------------------------------------------------------------------------------------------------------------------------
-def run_lp_batch(args, rank, local_rank, world):
+def lp_shard(args, rank):
     c4 = args.config == 4
     insts = load_instances(FIXTURE_C4 if c4 else FIXTURE)
     shard = [insts[i % len(insts)] for i in range(args.batch)]
     if rank > 0:
         shard = [relabel(I, 1000 * rank + i) for i, I in enumerate(shard)]
-    cpu = cpu_obj = cpu_it = None
-    if world == 1 and rank == 0:
-        sample = args.cpu_sample if args.cpu_sample is not None else (6 if c4 else 32)
-        pool = args.cpu_pool if args.cpu_pool is not None else (32 if c4 else args.batch)
-        if sample > 0:
-            cpu, cpu_obj, cpu_it = cpu_baseline_lp(shard, sample, pool, min(16, os.cpu_count() or 1))
+    return shard, len(insts)
 
-    local_rank, sync, allred, backend = gpu_dist_init(local_rank, world)
-    from lpbox_hip.lp import LpBatch
+
+def cpu_leg_lp(args, nested=False):
+    """cpu_baseline of configs 2 / 4 (rank 0 at N = 1 only), before the GPU is initialised."""
+    c4 = args.config == 4
+    sample = args.cpu_sample if args.cpu_sample is not None else ((3 if nested else 6) if c4 else 32)
+    if sample <= 0:
+        return None
+    shard, _ = lp_shard(args, 0)
+    ncpu = usable_cpus()
+    pool = args.cpu_pool if args.cpu_pool is not None else (min(args.batch, max(32, ncpu)) if c4 else args.batch)
+    return cpu_baseline_lp(shard, sample, pool, with_log=not c4)
+
+
+def run_lp_batch(args, ctx, cpu_leg=None):
+    rank, world, local_rank, sync, allred = ctx.rank, ctx.world, ctx.local_rank, ctx.sync, ctx.allred
+    c4 = args.config == 4
+    shard, n_distinct = lp_shard(args, rank)
+    cpu, cpu_obj, cpu_it = cpu_leg if cpu_leg is not None else (None, None, None)
+    if STUB:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from bench_stub import StubBatch as LpBatch
+    else:
+        from lpbox_hip.lp import LpBatch
     batch = LpBatch(shard, device=local_rank)
     cfg = batch.config()
 
@@ -281,7 +419,7 @@ def run_lp_batch(args, rank, local_rank, world):
     # Outside the timed region, config 2 only: the opt-in direct x-update (lpbox_set_x_update; NOT the reference's PCG, so it is reported
     # beside the headline, never as `value`) on the same batch
     direct = None
-    if not c4 and world == 1:
+    if not c4 and world == 1 and not STUB:
         try:
             batch.set_x_update("direct")
             batch.solve_init(); batch.solve_iter(0, MAX_ITERS)          # warm
@@ -306,6 +444,7 @@ def run_lp_batch(args, rank, local_rank, world):
 
     t_max = allred(dt, "MAX")
     it_total = allred(iters_per_step * args.steps, "SUM")
+    line = None
     if rank == 0:
         kernel_s = (k_ms / 1e3) / max(k_launches, 1)
         kname = "lp_window_kernel<%d,%d>" % (cfg["threads"], cfg["elems_per_thread"])
@@ -324,8 +463,8 @@ def run_lp_batch(args, rank, local_rank, world):
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": f"synthetic (reference generator, RandomState(0), first {min(B, len(insts))} draws {size}; rank r > 0: the same LPs "
-                    "relabelled by a rank-seeded permutation)",
+            "data": f"synthetic (reference generator, RandomState(0), first {min(B, n_distinct)} draws {size}; rank r > 0: the same LPs "
+                    "relabelled by a rank-seeded permutation)" + (" -- STUB SOLVER, launch-path test only, not a measurement" if STUB else ""),
             "config": {"workload": f"batch of {B} {size} combinatorial-auction LP instances per GPU, fp64, full solve "
                                    "(init + ADMM_lp_iters(0,2e4)) = 1 step (BASELINE configs[%d])" % (3 if c4 else 1),
                        "instances_per_gpu": B, "threads_per_instance": cfg["threads"], "slots_per_thread": cfg["elems_per_thread"],
@@ -347,6 +486,8 @@ def run_lp_batch(args, rank, local_rank, world):
             "detail": {"instance_iters_per_step": iters_per_step, "mean_outer_iters": float(outer.mean()),
                        "max_outer_iters": float(outer.max()), "mean_pcg_per_outer": float(pcg.sum() / outer.sum()),
                        "wall_clock_to_converge_ms": 1e3 * t_max / args.steps,
+                       # the lottery-free figure of the kernel: which instance is slowest, and for how many
+                       # iterations, is a draw of the summation order; time per iteration of that instance is not
                        "us_per_outer_iteration_slowest_instance": 1e6 * kernel_s / float(outer.max()),
                        "mean_objective": float(objs.mean()), "infeasible_instances": infeasible},
         }
@@ -363,15 +504,17 @@ def run_lp_batch(args, rank, local_rank, world):
                 "eigen_order_mean_outer_iters": float(cpu_it.mean()), "eigen_order_max_outer_iters": float(cpu_it.max()),
                 "note": "objective = sum of accepted bid prices (maximisation); the two summation orders end on different, "
                         "statistically equivalent binary solutions (DESIGN.md section 3)"}
-        print(json.dumps(line), flush=True)
-    finish(world)
+        if STUB:
+            line["stub"] = True
+    batch.close()
+    return line if rank == 0 else None
 
 
 # ------------------------------------------------------------------------------------------------------------------------
 # config 3: one full-resolution segmentation MRF
 # ------------------------------------------------------------------------------------------------------------------------
-def run_seg(args, rank, local_rank, world):
-    local_rank, sync, allred, backend = gpu_dist_init(local_rank, world)
+def run_seg(args, ctx, cpu_leg=None):
+    rank, world, local_rank, sync, allred = ctx.rank, ctx.world, ctx.local_rank, ctx.sync, ctx.allred
     from lpbox_hip.seg import PyLPboxADMMsolver, load_gray
     gray = load_gray(os.path.join(GOLDEN, "seg", "0.jpg"))       # the reference's own sample image 0 (500 x 375)
     s = PyLPboxADMMsolver(0, gray.size, rank)
@@ -399,6 +542,7 @@ def run_seg(args, rank, local_rank, world):
     bytes_solve = o * (3 * mA + 256 * n) + p * (mA + 104 * n)     # B_iter = 3 m_A + 8*32 n + K (m_A + 8*13 n)
     t_max = allred(dt, "MAX")
     it_total = allred(o * args.steps, "SUM")
+    line = None
     if rank == 0:
         chain_s = ms / 1e3 / args.steps
         line = {"metric": "admm_iters_per_sec_segmentation_mrf_full_resolution", "value": it_total / t_max, "unit": "iterations/s",
@@ -428,15 +572,15 @@ def run_seg(args, rank, local_rank, world):
             line["cpu_baseline"] = dict(value=so.total_outer_iters / dtc, unit="iterations/s", cores=1, kind="port",
                                         sample=f"the same full solve by oracle/seg_oracle.c: {so.total_outer_iters} iterations in {dtc:.1f} s",
                                         cpu_model=model, compiler=cc)
-        print(json.dumps(line), flush=True)
-    finish(world)
+    s.close()
+    return line
 
 
 # ------------------------------------------------------------------------------------------------------------------------
 # config 5: one large LP, variable-sharded over the ranks
 # ------------------------------------------------------------------------------------------------------------------------
-def run_big(args, rank, local_rank, world):
-    local_rank, sync, allred, backend = gpu_dist_init(local_rank, world)
+def run_big(args, ctx, cpu_leg=None):
+    rank, world, local_rank, sync, allred, backend = ctx.rank, ctx.world, ctx.local_rank, ctx.sync, ctx.allred, ctx.backend
     from lpbox_hip.big import BigLp
     from lpbox_hip.synth import make_auction_like
     n = int(args.variables)
@@ -458,6 +602,7 @@ def run_big(args, rank, local_rank, world):
     sync()
     dt = time.perf_counter() - t0
     t_max = allred(dt, "MAX")
+    line = None
     if rank == 0:
         o, p = g.scalar("outer_total"), g.scalar("pcg_total")        # of the last step
         per_iter = 1.0 / (args.steps * max(o, 1))
@@ -494,9 +639,11 @@ def run_big(args, rank, local_rank, world):
             line["cpu_baseline"] = dict(value=5 / dtc, unit="iterations/s", cores=1, kind="port",
                                         sample=f"first 5 iterations of the same instance by oracle/lpbox_oracle.c in {dtc:.1f} s",
                                         cpu_model=model, compiler=cc)
-        print(json.dumps(line), flush=True)
-    finish(world)
+    g.close()
+    return line
 
+
+RUN = {2: run_lp_batch, 4: run_lp_batch, 3: run_seg, 5: run_big}
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

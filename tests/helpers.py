@@ -48,6 +48,17 @@ def oracle_for(batch, idx, I, x_update="pcg", direct_rows=None):
                        batch.row_split(idx), batch.col_split(idx), x_update=x_update, direct_rows=direct_rows)
 
 
+def oracle_full_solve(args):
+    """Worker (CPU): one instance solved to convergence by the oracle in the kernels' association."""
+    I, T, npos, pos, rs, cs = args
+    s = O.LpOracle(0, order=O.ORDER_GPU, T=T, positions=pos, npos=npos, row_split=rs, col_split=cs)
+    s.set_problem(I["n"], I["l"], I["colptr"], I["rowidx"], I["b"])
+    s.solve_init()
+    ret = s.solve_iter(0, 20000)
+    return ret, s.total_outer_iters, s.total_pcg_iters, s.cal_Obj(), s.vec("x"), s.get_x_sol().ravel()
+
+
+
 # ------------------------------------------------------------------------------------------------
 # The reference's own validation loops (LP/trainer.py:_valid_2, SEG/trainer.py:_my_valid) driven on the CPU oracle:
 # adapters with the pyx surface that log every call, and a scripted stand-in for the trained network.

@@ -150,3 +150,78 @@ def test_alternating_window_lengths_leave_no_stale_columns():
         assert g.solve_iter_l2f(a, b, None, 0) == o.solve_iter_l2f(a, b, np.zeros(P["n"]), 0)
         assert bits_equal(g.get_x_iters_2d(30), o.get_x_iters_2d(30))
     assert not g.get_x_iters_2d(30)[:, 10:].any()
+
+
+def test_config5_early_fix_window_with_fused_policy_at_a_million_variables():
+    """BASELINE config 5's second half at its real size on one rank: a 100-iteration window of the n = 10^6 LP, the fused MHA policy
+    scoring all 10^6 variables straight from the device-resident x_iters, its fix vector applied in the next window.
+    Checked: (1) the packed x_iters of the window against the oracle, bit for bit, on a 10^4-row sample; (2) the policy's scores are
+    reproducible bit for bit and agree with the fp32 HIP network on the sample; (3) a second solver replays the whole sequence with
+    identical bits; (4) the window that applies the fixes against the oracle's real compaction (LPcpp:1124-1335): live iterate, duals,
+    f, counters; (5) the objective bookkeeping recomputed on the host from the problem data.
+    The reference ships no checkpoint: the network has reference-style random weights with the last layer scaled up so that its scores
+    spread beyond the 0.9 / 0.1 thresholds -- arbitrary decisions, which is all this arithmetic test needs."""
+    import torch
+    from lpbox_hip.big import BigLp
+    from lpbox_hip.policy import FusedEarlyFixPolicy, HipFp32Policy, random_state
+    from lpbox_hip.synth import make_auction_like
+    n, ws = 1000000, 100
+    P = make_auction_like(n, 0)
+    sd = random_state(20, 0)
+    sd["classify.fc4.weight"] = sd["classify.fc4.weight"] * 400.0
+    pol = FusedEarlyFixPolicy(sd, tokens=20)
+    sample = np.random.RandomState(0).choice(n, 10000, replace=False)
+    sample.sort()
+
+    def gpu_run():
+        g = BigLp(P, use_torch_stream=True)
+        g.solve_init()
+        assert g.solve_iter_l2f(0, ws, None, 0) == 0
+        X = g.x_iters_torch(ws)                                          # (n, ws) fp64 on the device, zero-copy
+        assert tuple(X.shape) == (n, ws)
+        off = torch.arange(n, device=X.device, dtype=torch.int64) * ws
+        sig = pol.scores_from_xiters(X.reshape(-1), off, ws // 20).reshape(-1)
+        vec = torch.where(sig > 0.9, 1.0, torch.where(sig < 0.1, 0.0, -1.0)).to(torch.float64).cpu().numpy()   # deter_fix_2, LP/trainer.py:101-135
+        xs = X[torch.as_tensor(sample, device=X.device)].cpu().numpy()
+        sig32 = HipFp32Policy(sd, tokens=20).scores_from_xiters(X.reshape(-1), off[torch.as_tensor(sample, device=X.device)], ws // 20).cpu().numpy()
+        num = int(np.count_nonzero(vec != -1))
+        ret = g.solve_iter_l2f(ws, ws + 10, vec, num)
+        return g, sig.cpu().numpy(), vec, num, xs, sig32, ret
+
+    g, sig, vec, num, xs, sig32, ret = gpu_run()
+    assert 10 < num < n and (vec == 1).any() and (vec == 0).any()
+    assert np.abs(sig[sample] - sig32).max() <= 2e-2                     # fp16 encoder vs the fp32 network (head scaled 400 x: stress)
+    band = (np.abs(sig32 - 0.9) > 3e-2) & (np.abs(sig32 - 0.1) > 3e-2)
+    assert np.array_equal((sig[sample] > 0.9)[band], (sig32 > 0.9)[band]) and np.array_equal((sig[sample] < 0.1)[band], (sig32 < 0.1)[band])
+
+    g2, sig2, vec2, num2, xs2, _, ret2 = gpu_run()                       # (3) determinism of the whole sequence
+    assert bits_equal(sig.astype(np.float64), sig2.astype(np.float64)) and np.array_equal(vec, vec2) and (num, ret) == (num2, ret2)
+    assert bits_equal(xs, xs2) and bits_equal(g.local_x(), g2.local_x()) and g.cal_Obj() == g2.cal_Obj()
+    g2.close()
+
+    o = _oracle(P, g)                                                    # about 50 s of CPU
+    assert o.solve_iter_l2f(0, ws, np.zeros(n), 0) == 0
+    assert bits_equal(xs, o.get_x_iters_2d(ws)[sample])                  # (1)
+    assert o.solve_iter_l2f(ws, ws + 10, vec, num) == ret                # (4)
+    assert g.get_n() == o.get_n() == n - num
+    left = o.vec("left_idx").astype(int)
+    assert np.array_equal(left, np.where(vec == -1)[0])
+    for name in ("x", "z1", "z2"):
+        assert bits_equal(g.vec(name)[left], o.vec(name)), name
+    for name in ("z4", "f"):
+        assert bits_equal(g.vec(name), o.vec(name)), name
+    for name in ("rho1", "gamma", "dI", "rho4Et", "cur_obj", "sum_fix_obj", "cvg1", "cvg2"):
+        assert g.scalar(name) == o.scalar(name), name
+    assert (g.scalar("outer_total"), g.scalar("pcg_total")) == (o.total_outer_iters, o.total_pcg_iters)
+    assert g.cal_Obj() == o.cal_Obj()
+    # (5) bookkeeping from the problem data: sum_fix_obj = b2 . x2 (LPcpp:1237-1249), cur_obj = b1 . round(x1) (:1555-1557),
+    # cal_obj = their sum (:1630-1642); the binary solution carries the fixed values in place (:1648-1665)
+    b = np.asarray(P["b"], np.float64)
+    fixed = vec != -1
+    assert abs(float(b[fixed] @ vec[fixed]) - g.scalar("sum_fix_obj")) <= 1e-9 * abs(g.scalar("sum_fix_obj"))
+    xb = g.local_x_sol()
+    assert np.array_equal(xb[fixed], vec[fixed]) and np.array_equal(xb[left], (g.local_x()[left] >= 0.5).astype(np.float64))
+    assert abs(float(b[left] @ xb[left]) - g.scalar("cur_obj")) <= 1e-9 * abs(g.scalar("cur_obj"))
+    assert g.cal_Obj() == g.scalar("sum_fix_obj") + g.scalar("cur_obj")
+    assert np.array_equal(xb, o.get_x_sol().ravel())
+    g.close()

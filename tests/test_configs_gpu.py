@@ -11,7 +11,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import bits_equal, lp_instances, oracle_for
+from helpers import bits_equal, lp_instances, oracle_for, oracle_full_solve
 
 pytestmark = pytest.mark.gpu
 
@@ -100,17 +100,6 @@ def test_config5_windows_bit_exact_at_full_size(n, seed):
         assert g.scalar("cur_obj") == o.scalar("cur_obj")
 
 
-def _oracle_full_solve(args):
-    """Worker (CPU): one instance solved to convergence by the oracle in the kernels' association."""
-    I, T, npos, pos, rs, cs = args
-    from oracle import oracle as O
-    s = O.LpOracle(0, order=O.ORDER_GPU, T=T, positions=pos, npos=npos, row_split=rs, col_split=cs)
-    s.set_problem(I["n"], I["l"], I["colptr"], I["rowidx"], I["b"])
-    s.solve_init()
-    ret = s.solve_iter(0, 20000)
-    return ret, s.total_outer_iters, s.total_pcg_iters, s.cal_Obj(), s.vec("x"), s.get_x_sol().ravel()
-
-
 @pytest.mark.parametrize("fixture,count", [("lp_100_500_seed0.npz", 256), ("lp_500_2000_seed0.npz", 48)])
 def test_every_benchmark_instance_bit_exact_to_convergence(fixture, count):
     """Not three spot checks: EVERY instance of the headline batch (and the first 48 of the config-4 batch) solved to convergence by the
@@ -124,8 +113,10 @@ def test_every_benchmark_instance_bit_exact_to_convergence(fixture, count):
     rets = B.solve_iter(0, 20000)
     cfg = B.config()
     jobs = [(I, cfg["threads"], cfg["threads"] * cfg["elems_per_thread"], B.layout(i), B.row_split(i), B.col_split(i)) for i, I in enumerate(insts)]
-    with ProcessPoolExecutor(min(16, os.cpu_count() or 1)) as ex:
-        res = list(ex.map(_oracle_full_solve, jobs, chunksize=2))
+    # spawn, not fork: this process has a live HIP runtime, and a forked copy of one is a hazard
+    import multiprocessing
+    with ProcessPoolExecutor(min(16, os.cpu_count() or 1), mp_context=multiprocessing.get_context("spawn")) as ex:
+        res = list(ex.map(oracle_full_solve, jobs, chunksize=2))
     for i, (ret, outer, pcg, obj, x, xs) in enumerate(res):
         assert int(rets[i]) == ret and B.counters(i) == (outer, pcg), i
         assert bits_equal(B.debug_vec("x", i), x) and B.cal_obj(i) == obj, i

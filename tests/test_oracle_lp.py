@@ -216,3 +216,18 @@ def test_instance_file_writer_roundtrip(tmp_path):
     o.read_files(pc, pb, 100)
     o.solve_init()
     assert o.get_n() == I["n"] and np.array_equal(o.vec("b"), I["b"])
+
+
+def test_oracle_pool_worker_under_spawn():
+    """The -m gpu parity test of every benchmark instance runs its oracle solves in a SPAWNED pool (a process that has initialised the GPU
+    must not fork): the worker has to be importable and picklable from a fresh interpreter, and equal an in-process solve."""
+    import multiprocessing
+    from concurrent.futures import ProcessPoolExecutor
+    from helpers import oracle_full_solve
+    insts = lp_instances("lp_20_60_seed0.npz")[:3]
+    jobs = [(I, 512, 512, None, None, None) for I in insts]
+    with ProcessPoolExecutor(2, mp_context=multiprocessing.get_context("spawn")) as ex:
+        res = list(ex.map(oracle_full_solve, jobs, chunksize=2))
+    for job, r in zip(jobs, res):
+        here = oracle_full_solve(job)
+        assert r[:4] == here[:4] and np.array_equal(r[4], here[4]) and np.array_equal(r[5], here[5])

@@ -95,6 +95,21 @@ def test_full_resolution_image_windows_bit_exact():
     compare_state(g, o, "full-res")
 
 
+def test_full_resolution_legacy_solve_bit_exact_to_convergence():
+    """BASELINE config 3 as bench.py runs it: ADMM_bqp_unconstrained_legacy (SEGcpp:1200-1380) on the full 187 500-variable problem, all
+    the way to its stop test -- energy, stop reason, outer and PCG iteration counts, final iterate and duals, binary solution."""
+    from lpbox_hip.seg import load_gray
+    n = load_gray(os.path.join(GOLDEN, "seg", "0.jpg")).size
+    g, o = make_pair(n)
+    eg, eo = g.solve_iter(), o.solve_iter()
+    assert eg == eo
+    assert g.stop() == (o.last_stop, o.legacy_iter_plus1)
+    assert g.counters() == (o.total_outer_iters, o.total_pcg_iters) and o.total_outer_iters > 300
+    assert np.array_equal(g.get_x_sol(), o.get_x_sol())
+    assert g.get_obj() == o.get_obj()
+    compare_state(g, o, "full-res final")
+
+
 def test_batched_legacy_solves_equal_individual_solves():
     """lpbox_seg_legacy_batch: several problems of DIFFERENT sizes advanced in lockstep by one launch chain; each must come out
     bit-identical to its own solve_init() + solve_iter() (own control state, own PCG / outer iteration counts, own stop)."""
