@@ -278,6 +278,8 @@ int lpbox_big_set_stream(lpbox_big_t *h, void *hip_stream) {
 
 int lpbox_big_set_allgather(lpbox_big_t *h, lpbox_allgather_fn fn, void *user) {
     if (!h) return lpbox_fail(LPBOX_E_BADHANDLE, "bad handle");
+    // the exchange buffers are sized by lpbox_big_init from the transport that is set then (as for lpbox_big_rccl_init)
+    if (h->inited) return lpbox_fail(LPBOX_E_STATE, "set the all-gather callback before lpbox_big_init");
     h->ag = fn; h->ag_user = user;
     return LPBOX_OK;
 }

@@ -180,13 +180,13 @@ int finalize(lpbox_t *h) {
     while (EPT < max_ept && (long)T * EPT < big) EPT *= 2;
     if ((long)T * EPT < big && T == 512) { T = 256; EPT = 1; while (EPT < 8 && (long)T * EPT < big) EPT *= 2; }
     if ((long)T * EPT < big)
-        return fail(LPBOX_E_UNSUPPORTED, "instance with max(n,l)=%d exceeds the on-chip kernel's %d register slots", big, T * EPT);
+        return fail(LPBOX_E_TOOLARGE, "instance with max(n,l)=%d exceeds the on-chip kernel's %d register slots", big, T * EPT);
     h->colsplit = T == 512 || T == 1024 || (T == 256 && EPT == 2);              // variants compiled with helper lists (LP_DISPATCH)
     h->T = T; h->EPT = EPT;
     h->NS = T * EPT;                       // storage positions / row-task slots per instance
     h->LS = (lmax + 31) & ~31; h->ZS = (zmax + 7) & ~7;     // LS: a whole number of 32-row bank classes
     h->lds = lp_window_lds_bytes(T, h->NS, h->LS, h->ZS);
-    if (h->lds > 160 * 1024) return fail(LPBOX_E_UNSUPPORTED, "instance needs %zu B of LDS (> 160 KiB per CU)", h->lds);
+    if (h->lds > 160 * 1024) return fail(LPBOX_E_TOOLARGE, "instance needs %zu B of LDS (> 160 KiB per CU)", h->lds);
 
     if (!h->stream) HIPCHK(hipStreamCreate(&h->stream));
     if (!h->ev0) { HIPCHK(hipEventCreate(&h->ev0)); HIPCHK(hipEventCreate(&h->ev1)); }
@@ -1218,6 +1218,7 @@ int lpbox_get_direct_rows(lpbox_t *h, int idx, int *gidx_of_row) {
     if (h->seg) return fail(LPBOX_E_STATE, "this entry point belongs to the LP flavour");
     const LpInstance &I = h->inst[idx];
     if ((int)I.dir_g.size() != I.l) return fail(LPBOX_E_STATE, "lpbox_set_x_update(LPBOX_XUPDATE_DIRECT) has not been called");
+    if (!gidx_of_row) return fail(LPBOX_E_BADARG, "null output");
     for (int r = 0; r < I.l; r++) gidx_of_row[r] = I.dir_g[r];
     return I.nG;
 }

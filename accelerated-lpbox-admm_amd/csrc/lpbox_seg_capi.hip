@@ -388,7 +388,12 @@ int segc_legacy_batch(SegSolver **ss, int B, int *energies) {
         if (!ss[i] || !ss[i]->has_problem) return lpbox_fail(LPBOX_E_STATE, "problem %d of the batch has no image / problem", i);
         if (ss[i]->device != s0->device) return lpbox_fail(LPBOX_E_BADARG, "all problems of a batch must live on one device");
         if (ss[i]->record > 0) return lpbox_fail(LPBOX_E_UNSUPPORTED, "recording is per-solver (lpbox_seg_legacy)");
+        for (int k = 0; k < i; k++)                                 // one handle twice = every launch advancing the same buffers twice
+            if (ss[k] == ss[i]) return lpbox_fail(LPBOX_E_BADARG, "problem %d and problem %d of the batch are the same handle", k, i);
     }
+    // a solver counts as initialised only once the whole chain has completed: an early error return leaves every member of the
+    // batch in the "solve_init has not been called" state instead of flagged ready with half-written device state
+    for (int i = 0; i < B; i++) { ss[i]->inited = false; ss[i]->xi_valid = false; }
     int rc = LPBOX_OK;
     int Gmax = 0;
     for (int i = 0; i < B; i++) {                                   // upload + host-side reset of segc_init (the init KERNEL runs batched)
@@ -398,7 +403,6 @@ int segc_legacy_batch(SegSolver **ss, int B, int *energies) {
         HIPCHK(hipMemcpyAsync(s->b.p, s->orgb.data(), sizeof(double) * (size_t)s->n, hipMemcpyHostToDevice, s->stream));
         s->left_idx.resize(s->n);
         for (int k = 0; k < s->n; k++) s->left_idx[k] = k;
-        s->xi_valid = false; s->parity = 0; s->inited = true;
         Gmax = std::max(Gmax, s->G);
     }
     for (int i = 0; i < B; i++) HIPCHK(hipStreamSynchronize(ss[i]->stream));
@@ -406,6 +410,7 @@ int segc_legacy_batch(SegSolver **ss, int B, int *energies) {
     std::vector<SegDev> hd(B);
     for (int i = 0; i < B; i++) hd[i] = ss[i]->dev();
     Buf<SegDev> devs; Buf<SegState> dstates;
+    struct Release { Buf<SegDev> &a; Buf<SegState> &b; ~Release() { a.release(); b.release(); } } release_on_exit{devs, dstates};
     HIPCHK(devs.alloc(B)); HIPCHK(dstates.alloc(B));
     HIPCHK(hipMemcpyAsync(devs.p, hd.data(), sizeof(SegDev) * (size_t)B, hipMemcpyHostToDevice, st));
     std::vector<SegState> hs(B);
@@ -424,7 +429,7 @@ int segc_legacy_batch(SegSolver **ss, int B, int *energies) {
     launches += 2;
     for (;;) {
         rc = read_states();
-        if (rc) { devs.release(); dstates.release(); return rc; }
+        if (rc) return rc;
         bool more = false, any_run = false;
         int remaining = 0, pcg_max = 0, pcg_k = 0;
         for (int i = 0; i < B; i++) {
@@ -455,11 +460,10 @@ int segc_legacy_batch(SegSolver **ss, int B, int *energies) {
     HIPCHK(hipEventElapsedTime(&ms, s0->ev0, s0->ev1));
     for (int i = 0; i < B; i++) {
         SegSolver *s = ss[i];
-        s->hst = hs[i]; s->parity = parity; s->rec_cols = 0; s->xi_valid = false;
+        s->hst = hs[i]; s->parity = parity; s->rec_cols = 0; s->xi_valid = false; s->inited = true;
         if (energies) energies[i] = (int)(s->hst.cur_obj + s->c);     // :1379
     }
     s0->kernel_ms += ms; s0->launches += launches;
-    devs.release(); dstates.release();
     return LPBOX_OK;
 }
 

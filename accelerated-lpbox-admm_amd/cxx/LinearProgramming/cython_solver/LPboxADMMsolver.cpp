@@ -110,6 +110,7 @@ inline void LPboxADMMsolver::set_problem(int n, int l, const int *colptr, const 
 
 inline int LPboxADMMsolver::ADMM_lp_iters_init() {
     State &s = *s_;
+    s.x_prev.clear();                                      // x_prev = Zero(n) (LPcpp:572)
     if (!s.big) {
         int n = 0, l = 0, nnz = 0;
         lpbox_ok(lpbox_get_problem_lp(s.h, 0, &n, &l, &nnz, nullptr, nullptr, nullptr, nullptr), "lpbox_get_problem_lp");
@@ -118,8 +119,7 @@ inline int LPboxADMMsolver::ADMM_lp_iters_init() {
         if (fits) {
             const int rc = lpbox_init(s.h);
             if (rc >= 0) return rc;
-            const char *m = lpbox_last_error();
-            if (!(rc == LPBOX_E_UNSUPPORTED && m && std::string(m).find("of LDS") != std::string::npos)) lpbox_throw("lpbox_init");
+            if (rc != LPBOX_E_TOOLARGE) lpbox_throw("lpbox_init");
         }
         // does not fit one CU: the same algorithm on the large-instance path, one rank
         std::vector<int> colptr((size_t)n + 1), rowidx((size_t)std::max(nnz, 1));

@@ -147,12 +147,17 @@ def load():
 
 
 class LpboxError(RuntimeError):
-    pass
+    code = None          # the LPBOX_E_* status that was returned
+
+
+E_TOOLARGE = -9          # include/lpbox_hip.h: LPBOX_E_TOOLARGE
 
 
 def check(rc, what="lpbox call"):
     """Turn a negative status into a Python exception carrying lpbox_last_error()."""
     if rc is not None and rc < 0:
         msg = load().lpbox_last_error()
-        raise LpboxError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+        err = LpboxError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+        err.code = rc
+        raise err
     return rc

@@ -13,7 +13,7 @@ import time
 import numpy as np
 
 from . import _lib, files
-from ._lib import LpboxError, check  # noqa: F401
+from ._lib import E_TOOLARGE, LpboxError, check  # noqa: F401
 
 STOP_NAMES = {0: None, 1: "y1_y2", 2: "obj_std", 3: "pcg_alpha_negative", 4: "all_fixed"}
 
@@ -374,6 +374,7 @@ class PyLPboxADMMsolver:
 
     def _small(self):
         """A new problem on an object that had been routed to the large path starts from the on-chip handle again."""
+        self._x_prev = None
         if not isinstance(self._b, LpBatch):
             self._b.close()
             self._b = LpBatch(batch=1, print_info=self.print_info)
@@ -394,6 +395,7 @@ class PyLPboxADMMsolver:
 
     # LP pyx:19-20
     def solve_init(self):
+        self._x_prev = None                                # x_prev = Zero(n) in ADMM_lp_iters_init (LPcpp:572)
         if isinstance(self._b, LpBatch):
             P = self._b.get_problem(0)
             fits = max(P["n"], P["l"]) <= ONCHIP_MAX
@@ -401,7 +403,7 @@ class PyLPboxADMMsolver:
                 try:
                     return self._b.solve_init()
                 except LpboxError as e:                    # fits the register slots but not the CU's 160 KiB of LDS (very dense E)
-                    if "of LDS" not in str(e):
+                    if e.code != E_TOOLARGE:
                         raise
             small = self._b                                # does not fit one CU: same algorithm on the multi-kernel path
             self._b = _LargeInstance(P)

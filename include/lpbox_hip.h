@@ -32,6 +32,8 @@ extern "C" {
 #define LPBOX_E_NODEVICE   -6
 #define LPBOX_E_UNSUPPORTED -7  /* instance outside what the persistent kernels hold on-chip */
 #define LPBOX_E_NOMEM      -8
+#define LPBOX_E_TOOLARGE   -9   /* lpbox_init: the instance fits neither the register slots nor the LDS of one CU -- same algorithm,
+                                   other entry points: lpbox_big_* (the drop-in classes route there by this code, not by the text) */
 
 #define LPBOX_FLAVOUR_LP   0    /* min b'x  s.t. Ex<=f, x in {0,1}^n      (LPcpp) */
 #define LPBOX_FLAVOUR_SEG  1    /* min x'Ax + b'x, x in {0,1}^n           (SEGcpp) */

@@ -131,6 +131,54 @@ def test_jpeg_reader_equals_libjpeg_luminance(tmp_path):
     assert np.array_equal(load_gray(odd), np.asarray(im.convert("L"), dtype=np.uint8))
 
 
+def _patch_sof_sampling(data, comp, hv):
+    """Return the JPEG bytes with the sampling-factor byte of frame component `comp` replaced by `hv` (e.g. 0x22)."""
+    m = bytearray(data)
+    i = 2
+    while i + 4 <= len(m):
+        assert m[i] == 0xFF
+        mk, L = m[i + 1], (m[i + 2] << 8) | m[i + 3]
+        if mk in (0xC0, 0xC1):
+            m[i + 4 + 6 + 3 * comp + 1] = hv
+            return bytes(m)
+        i += 2 + L
+    raise AssertionError("no SOF")
+
+
+def test_jpeg_sampling_factor_corner_cases(tmp_path):
+    """(1) A one-component JPEG whose frame header states sampling factors other than 1x1 is still one 8x8 block per MCU in raster order
+    (T.81 A.2.2; libjpeg ignores the factors when comps_in_scan == 1): the reader must decode it pixel for pixel like libjpeg (PIL).
+    (2) A colour file whose luminance is NOT the most finely sampled component (Y 1x1, Cb 2x2) would need libjpeg's upsampling of Y:
+    refused with a reason -- in the previous round this file read past the end of the luminance plane."""
+    PIL = pytest.importorskip("PIL.Image")
+    from lpbox_hip.seg import load_gray
+    from lpbox_hip import _lib
+    import ctypes as C
+    L = _lib.load()
+    rng = np.random.RandomState(3)
+    gray = str(tmp_path / "gray.jpg")
+    PIL.fromarray((rng.rand(45, 70) * 255).astype(np.uint8)).save(gray, quality=90)
+    for hv in (0x22, 0x21, 0x14):
+        patched = str(tmp_path / ("gray_%02x.jpg" % hv))
+        open(patched, "wb").write(_patch_sof_sampling(open(gray, "rb").read(), 0, hv))
+        ref = np.asarray(PIL.open(patched).convert("L"), dtype=np.uint8)
+        assert np.array_equal(ref, np.asarray(PIL.open(gray).convert("L"), dtype=np.uint8))      # libjpeg does ignore the factors
+        r, c = C.c_int(), C.c_int()
+        assert L.lpbox_read_jpeg_gray(patched.encode(), None, 0, C.byref(r), C.byref(c)) == 0 and (r.value, c.value) == ref.shape
+        out = np.zeros(ref.shape, np.uint8)
+        assert L.lpbox_read_jpeg_gray(patched.encode(), out.ctypes.data_as(C.c_void_p), out.size, C.byref(r), C.byref(c)) == 0
+        assert np.array_equal(out, ref), hex(hv)
+    src = open(os.path.join(GOLDEN, "seg", "0.jpg"), "rb").read()
+    bad = _patch_sof_sampling(_patch_sof_sampling(src, 0, 0x11), 1, 0x22)
+    path = str(tmp_path / "y_subsampled.jpg")
+    open(path, "wb").write(bad)
+    r, c = C.c_int(), C.c_int()
+    assert L.lpbox_read_jpeg_gray(path.encode(), None, 0, C.byref(r), C.byref(c)) == 0           # size query: header only
+    out = np.zeros(r.value * c.value, np.uint8)
+    assert L.lpbox_read_jpeg_gray(path.encode(), out.ctypes.data_as(C.c_void_p), out.size, C.byref(r), C.byref(c)) == -2
+    assert b"luminance is subsampled" in L.lpbox_last_error()
+
+
 def test_jpeg_reader_survives_damaged_files(tmp_path):
     """Truncated files and files with flipped bytes are either refused or decoded to SOME image -- never a crash or an out-of-bounds
     access (the same mutations ran 6 000 times under AddressSanitizer + UBSan on the CPU build of csrc/lpbox_jpeg_host.cpp while it was

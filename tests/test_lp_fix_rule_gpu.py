@@ -52,3 +52,20 @@ def test_rule_with_unreachable_consistency_is_the_l2f_loop():
             break
     assert a.get_n() == b.get_n() == I["n"]
     assert bits_equal(a.get_final_x_sol(), b.get_final_x_sol()) and a.cal_Obj() == b.cal_Obj()
+
+
+def test_reinit_resets_the_persistence_memory():
+    """ADMM_lp_iters_init sets x_prev = Zero(n) (LPcpp:572): a second solve on the same object must take the decisions of a fresh object,
+    not compare its first iterates with the last iterate of the solve before."""
+    I = lp_instances("lp_100_500_seed0.npz")[1]
+    a = _solver(I)
+    a.solve_iter_fix(0, 300, min_fix=10)
+    assert a.get_n() < I["n"]
+    a.set_problem(I["n"], I["l"], I["colptr"], I["rowidx"], I["b"])     # same size: the stale vector would have fitted
+    a.solve_init()
+    b = _solver(I)
+    for s in (a, b):
+        s.solve_init()                                                   # re-init alone must reset as well
+    ra, rb = a.solve_iter_fix(0, 300, min_fix=10), b.solve_iter_fix(0, 300, min_fix=10)
+    assert ra == rb and a.get_n() == b.get_n()
+    assert bits_equal(a.get_final_x_sol(), b.get_final_x_sol()) and a.cal_Obj() == b.cal_Obj()

@@ -142,6 +142,24 @@ def test_batched_legacy_solves_equal_individual_solves():
     assert batch[1].solve_iter() == ref[1][0]
 
 
+def test_batch_refuses_a_handle_listed_twice_and_leaves_the_solvers_usable():
+    from lpbox_hip.lp import LpboxError
+    from lpbox_hip.seg import PyLPboxADMMsolver, load_gray, solve_batch
+    gray = load_gray(os.path.join(GOLDEN, "seg", "7.jpg"))
+    a, b = PyLPboxADMMsolver(0, 2500, 0), PyLPboxADMMsolver(0, 2500, 1)
+    for s in (a, b):
+        s.write_files = False
+        s.set_image(gray)
+    with pytest.raises(LpboxError, match="same handle"):
+        solve_batch([a, b, a])
+    with pytest.raises(LpboxError, match="solve_init has not been called"):     # nobody was flagged initialised by the refused call
+        a.solve_iter_l2f(0, 10, np.zeros(a.get_org_n()), 0)
+    ea, eb = solve_batch([a, b])
+    assert ea == eb
+    a.solve_init()
+    assert a.solve_iter() == ea
+
+
 def test_alternating_window_lengths_leave_no_stale_columns():
     """x_iters = Zero(n, 10) on every l2f call (SEGcpp:924): a 3-iteration window after a 10-iteration one shows zeros in columns 3..9."""
     g, o = make_pair(2500, "7.jpg")
