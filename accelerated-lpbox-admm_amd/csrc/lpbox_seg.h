@@ -57,6 +57,13 @@ struct SegDev {
     int n, nnz, G, EPT;                    // G workgroups of SEG_T threads, EPT slots each
     // A_ptr (row-major, ascending columns; SEGh:17) in ELL form: slot k of row i at [k*n + i], rowlen[i] slots used
     const int *ecol; const double *eval; const uint8_t *rowlen; int ell_w;
+    // ... or, when the matrix has at most three diagonals either side of the main one and every off-diagonal value is -w with an
+    // integer w in 0..255 (the image problems: offsets -ncols, -(ncols-1), -1, +1, ncols-1, ncols and w = round(3 exp(.)) in 0..3,
+    // SEGcpp:144-224), as DIAGONALS: slot k of row i is column i + doff[k] (slot 3 = the main diagonal, value adiag[i]); the six
+    // off-diagonal weights of a row are the low six bytes of dpack[i].  A slot whose entry does not exist has w = 0 and contributes
+    // (-0.0) * v = +-0.0 to the row sum in the same ascending-column position -- the sum's bits are those of the stored entries alone.
+    // 16 B of matrix per row instead of 84, and the gathers need no index loads.
+    int dia; int doff[7]; const unsigned long long *dpack; const double *adiag;
     double *x, *y1, *y2, *z1, *z2, *b, *rhs, *r, *z, *tmp, *dinv, *td, *p0, *p1;
     uint8_t *live;          // 1 live, 0 fixed (x = 0 there; the fixed value is kept in fixval)
     uint8_t *fixval;

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 #define HIPCHK(expr)                                                                                         \
@@ -48,6 +49,8 @@ struct SegSolver {
     Buf<int> d_ecol, d_left;
     Buf<uint8_t> d_rowlen;
     int ell_w = 0;
+    bool dia = false; int doff[7] = {0, 0, 0, 0, 0, 0, 0};      // diagonal storage of the matrix (SegDev::dia), chosen by upload()
+    Buf<unsigned long long> d_dpack; Buf<double> d_adiag;
     Buf<double> d_eval, x, y1, y2, z1, z2, b, rhs, r, z, tmp, dinv, td, p0, p1, part, xhist, xi_out;
     Buf<uint8_t> live, fixval, newfix;
     Buf<SegState> st;
@@ -60,6 +63,8 @@ struct SegSolver {
         SegDev d;
         d.n = n; d.nnz = nnz; d.G = G; d.EPT = EPT;
         d.ecol = d_ecol.p; d.eval = d_eval.p; d.rowlen = d_rowlen.p; d.ell_w = ell_w;
+        d.dia = dia ? 1 : 0; d.dpack = d_dpack.p; d.adiag = d_adiag.p;
+        for (int k = 0; k < 7; k++) d.doff[k] = doff[k];
         d.x = x.p; d.y1 = y1.p; d.y2 = y2.p; d.z1 = z1.p; d.z2 = z2.p; d.b = b.p; d.rhs = rhs.p; d.r = r.p; d.z = z.p;
         d.tmp = tmp.p; d.dinv = dinv.p; d.td = td.p; d.p0 = p0.p; d.p1 = p1.p; d.live = live.p; d.fixval = fixval.p;
         d.newfix = newfix.p; d.part = part.p; d.xhist = xhist.p; d.ws_cap = ws_cap; d.st = st.p;
@@ -170,6 +175,49 @@ void build_costs(const unsigned char *gray, int rows, int cols, std::vector<int>
     rowptr[n] = (int)colidx.size();
 }
 
+// Can the matrix be held as diagonals (SegDev::dia)?  At most three distinct column offsets either side of the main diagonal, a stored
+// diagonal entry in every row, every off-diagonal value equal to -w for an integer w in 0..255.  True for every problem the image cost
+// builder makes (SEGcpp:144-248: offsets {+-1, +-(ncols-1), +-ncols}, w = round(3 exp(.))); anything else keeps the ELL form.
+bool as_diagonals(const SegSolver *s, std::vector<unsigned long long> &dpack, std::vector<double> &adiag) {
+    const int n = s->n;
+    std::vector<int> neg, pos;
+    auto note = [](std::vector<int> &v, int off) {
+        for (int o : v) if (o == off) return true;
+        if (v.size() == 3) return false;
+        v.push_back(off);
+        return true;
+    };
+    for (int i = 0; i < n; i++) {
+        bool have_diag = false;
+        for (int k = s->rowptr[i]; k < s->rowptr[i + 1]; k++) {
+            const int off = s->colidx[k] - i;
+            if (off == 0) { have_diag = true; continue; }
+            const double v = s->vals[k];
+            if (!(v <= 0.0 && v >= -255.0 && v == std::floor(v))) return false;
+            if (!note(off < 0 ? neg : pos, off)) return false;
+        }
+        if (!have_diag) return false;
+    }
+    std::sort(neg.begin(), neg.end()); std::sort(pos.begin(), pos.end());
+    int *doff = const_cast<SegSolver *>(s)->doff;
+    // slots 0..2: negative offsets ascending (missing ones in front), 3: the diagonal, 4..6: positive ascending (missing ones behind);
+    // a missing slot points at a harmless neighbour and carries w = 0 in every row
+    for (int k = 0; k < 3; k++) doff[k] = -1, doff[4 + k] = 1;
+    doff[3] = 0;
+    std::vector<std::pair<int, int>> slot_of;                     // (offset, byte of dpack)
+    for (size_t k = 0; k < neg.size(); k++) { const int q = 3 - (int)neg.size() + (int)k; doff[q] = neg[k]; slot_of.push_back({neg[k], q}); }
+    for (size_t k = 0; k < pos.size(); k++) { const int q = 4 + (int)k; doff[q] = pos[k]; slot_of.push_back({pos[k], q - 1}); }
+    dpack.assign((size_t)n, 0ull); adiag.assign((size_t)n, 0.0);
+    for (int i = 0; i < n; i++)
+        for (int k = s->rowptr[i]; k < s->rowptr[i + 1]; k++) {
+            const int off = s->colidx[k] - i;
+            if (off == 0) { adiag[i] = s->vals[k]; continue; }
+            for (auto &so : slot_of)
+                if (so.first == off) dpack[i] |= (unsigned long long)(unsigned)(-s->vals[k]) << (8 * so.second);
+        }
+    return true;
+}
+
 int upload(SegSolver *s) {
     int rc = use_device(s);
     if (rc) return rc;
@@ -185,12 +233,23 @@ int upload(SegSolver *s) {
     for (int i = 0; i < n; i++) w = std::max(w, s->rowptr[i + 1] - s->rowptr[i]);
     if (w > 255) return lpbox_fail(LPBOX_E_UNSUPPORTED, "a row of A stores %d entries; the ELL layout of the segmentation kernels holds at most 255", w);
     s->ell_w = w;
-    HIPCHK(s->d_ecol.alloc((size_t)w * n)); HIPCHK(s->d_eval.alloc((size_t)w * n)); HIPCHK(s->d_rowlen.alloc(n)); HIPCHK(s->d_left.alloc(n));
+    std::vector<unsigned long long> dpack; std::vector<double> adiag;
+    s->dia = n >= 2 && w <= 7 && !getenv("LPBOX_SEG_NODIA") && as_diagonals(s, dpack, adiag);      // LPBOX_SEG_NODIA: keep ELL (A/B, tests)
+    if (s->dia) {
+        s->d_ecol.release(); s->d_eval.release();
+        HIPCHK(s->d_dpack.alloc(n)); HIPCHK(s->d_adiag.alloc(n));
+        HIPCHK(hipMemcpy(s->d_dpack.p, dpack.data(), sizeof(unsigned long long) * (size_t)n, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(s->d_adiag.p, adiag.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+    } else {
+        s->d_dpack.release(); s->d_adiag.release();
+        HIPCHK(s->d_ecol.alloc((size_t)w * n)); HIPCHK(s->d_eval.alloc((size_t)w * n));
+    }
+    HIPCHK(s->d_rowlen.alloc(n)); HIPCHK(s->d_left.alloc(n));
     for (Buf<double> *bp : {&s->x, &s->y1, &s->y2, &s->z1, &s->z2, &s->b, &s->rhs, &s->r, &s->z, &s->tmp, &s->dinv, &s->td, &s->p0, &s->p1})
         HIPCHK(bp->alloc(n));
     HIPCHK(s->live.alloc(n)); HIPCHK(s->fixval.alloc(n)); HIPCHK(s->newfix.alloc(n));
     HIPCHK(s->part.alloc((size_t)5 * SEG_NPART * s->G)); HIPCHK(s->st.alloc(2));
-    {
+    if (!s->dia) {
         std::vector<int> ecol((size_t)w * n); std::vector<double> eval((size_t)w * n, 0.0); std::vector<uint8_t> rl(n);
         for (int i = 0; i < n; i++) {
             const int len = s->rowptr[i + 1] - s->rowptr[i];
@@ -299,7 +358,7 @@ void segc_destroy(SegSolver *s) {
     if (s->uploaded) (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     drop_graphs(s);
-    s->d_ecol.release(); s->d_rowlen.release(); s->d_left.release(); s->d_eval.release();
+    s->d_ecol.release(); s->d_rowlen.release(); s->d_left.release(); s->d_eval.release(); s->d_dpack.release(); s->d_adiag.release();
     for (Buf<double> *bp : {&s->x, &s->y1, &s->y2, &s->z1, &s->z2, &s->b, &s->rhs, &s->r, &s->z, &s->tmp, &s->dinv, &s->td, &s->p0, &s->p1,
                             &s->part, &s->xhist, &s->xi_out})
         bp->release();
@@ -642,6 +701,7 @@ int segc_debug_scalar(SegSolver *s, const char *name, double *out) {
     struct { const char *n; double v; } tab[] = {
         {"rho1", h.rho1}, {"gamma", h.gamma_val}, {"cur_obj", h.cur_obj}, {"std_obj", h.std_obj}, {"cvg1", h.cvg1}, {"cvg2", h.cvg2},
         {"obj_val", h.obj_val}, {"best_bin_obj", h.best_bin_obj}, {"c", s->c}, {"last_pcg", (double)h.last_pcg}, {"iter", (double)h.iter},
+        {"matrix_as_diagonals", s->dia ? 1.0 : 0.0},
     };
     for (auto &e : tab) if (!strcmp(e.n, name)) { *out = e.v; return LPBOX_OK; }
     return lpbox_fail(LPBOX_E_BADARG, "unknown scalar '%s'", name);

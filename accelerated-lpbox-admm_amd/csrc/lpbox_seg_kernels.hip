@@ -70,38 +70,6 @@ __device__ __forceinline__ void forward_state(const SegDev &d, int in, int out) 
     if (LEADER) d.st[out] = d.st[in];
 }
 
-// (2A + (rho1+rho2) I) row i times a gathered vector: diagonal entry = td[i], off-diagonal = 2*A_ik (SEGcpp:784-786).
-// The matrix is held in ELL form (slot k of row i at [k*n + i], ascending columns): consecutive lanes = consecutive rows
-// read consecutive addresses, and the 7-diagonal structure makes the gathers of v coalesced as well.
-template <typename GET>
-__device__ __forceinline__ double tm_row(const SegDev &d, int i, GET get) {
-    double tmp = 0;
-    const int len = d.rowlen[i];
-    const double tdi = d.td[i];
-    if (d.ell_w <= 8) {
-        // rows of the image problems have <= 7 entries: fetch all indices, then all values, then all gathered elements before the
-        // (ordered) additions, so that the loads of one row are in flight together
-        int c[8]; double v[8], g[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) if (k < len) c[k] = d.ecol[(size_t)k * d.n + i];
-#pragma unroll
-        for (int k = 0; k < 8; k++) if (k < len) v[k] = d.eval[(size_t)k * d.n + i];
-#pragma unroll
-        for (int k = 0; k < 8; k++) if (k < len) g[k] = get(c[k]);
-#pragma unroll
-        for (int k = 0; k < 8; k++) if (k < len) tmp += ((c[k] == i) ? tdi : 2 * v[k]) * g[k];
-    } else {
-        for (int k = 0; k < len; k++) {
-            const int c = d.ecol[(size_t)k * d.n + i];
-            const double val = (c == i) ? tdi : 2 * d.eval[(size_t)k * d.n + i];
-            tmp += val * get(c);
-        }
-    }
-    double res = 0.0;
-    res += 1.0 * tmp;
-    return res;
-}
-
 // The same row product in three separable steps, for the kernels that handle the two rows of a thread TOGETHER (image problems:
 // ell_w <= 8, EPT == 2): these launches are a few microseconds long and bound by the chain of dependent memory round trips of one
 // thread, not by bandwidth -- a row at a time costs row length -> indices/values -> gathered elements -> result store, and the second
@@ -110,8 +78,24 @@ __device__ __forceinline__ double tm_row(const SegDev &d, int i, GET get) {
 // order.  Padded slots hold column i and value 0 (lpbox_seg_capi.hip), so all ell_w slots are read and the length only masks the sum.
 struct EllRow { int len; double tdi; int c[8]; double v[8]; };
 __device__ __forceinline__ void ell_load(const SegDev &d, int i, EllRow &R) {
-    R.len = d.rowlen[i];
     R.tdi = d.td[i];
+    if (d.dia) {                                                             // diagonal storage (uniform branch): see SegDev
+        const unsigned long long pk = d.dpack[i];
+        const double aii = d.adiag[i];
+        const int other = i ? i - 1 : 1;                                     // an in-range column != i for the slots that do not exist
+        R.len = 7;
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+            if (k == 3) { R.c[k] = i; R.v[k] = aii; continue; }
+            const int s = k < 3 ? k : k - 1;
+            const int ci = i + d.doff[k];
+            R.c[k] = (unsigned)ci < (unsigned)d.n ? ci : other;
+            R.v[k] = -(double)(unsigned)((pk >> (8 * s)) & 255ull);
+        }
+        R.c[7] = i; R.v[7] = 0.0;
+        return;
+    }
+    R.len = d.rowlen[i];
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         const bool in = k < d.ell_w;
@@ -128,6 +112,35 @@ __device__ __forceinline__ double ell_sum(const EllRow &R, int i, const double (
     return res;
 }
 
+// (2A + (rho1+rho2) I) row i times a gathered vector: diagonal entry = td[i], off-diagonal = 2*A_ik (SEGcpp:784-786).
+// The matrix is held in ELL form (slot k of row i at [k*n + i], ascending columns): consecutive lanes = consecutive rows
+// read consecutive addresses, and the 7-diagonal structure makes the gathers of v coalesced as well.
+template <typename GET>
+__device__ __forceinline__ double tm_row(const SegDev &d, int i, GET get) {
+    double tmp = 0;
+    if (d.ell_w <= 8) {
+        // rows of the image problems have <= 7 entries: fetch all indices, then all values, then all gathered elements before the
+        // (ordered) additions, so that the loads of one row are in flight together
+        EllRow R;
+        ell_load(d, i, R);
+        double g[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) g[k] = get(R.c[k]);
+        return ell_sum(R, i, g);
+    } else {
+        const int len = d.rowlen[i];
+        const double tdi = d.td[i];
+        for (int k = 0; k < len; k++) {
+            const int c = d.ecol[(size_t)k * d.n + i];
+            const double val = (c == i) ? tdi : 2 * d.eval[(size_t)k * d.n + i];
+            tmp += val * get(c);
+        }
+    }
+    double res = 0.0;
+    res += 1.0 * tmp;
+    return res;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void seg_b_init(const SegDev &d, double c1) {      // ADMM_bqp_unconstrained_init SEGcpp:658-810
     for (int s = 0; s < d.EPT; s++) {
@@ -136,7 +149,8 @@ __device__ __forceinline__ void seg_b_init(const SegDev &d, double c1) {      //
         d.x[i] = 0.0; d.y1[i] = 0.0; d.y2[i] = 0.0; d.z1[i] = 0.0; d.z2[i] = 0.0;   // :762-777
         d.live[i] = 1; d.fixval[i] = 0;
         double aii = 0.0;
-        for (int k = 0; k < d.rowlen[i]; k++) if (d.ecol[(size_t)k * d.n + i] == i) aii = d.eval[(size_t)k * d.n + i];
+        if (d.dia) aii = d.adiag[i];
+        else for (int k = 0; k < d.rowlen[i]; k++) if (d.ecol[(size_t)k * d.n + i] == i) aii = d.eval[(size_t)k * d.n + i];
         double t = 2 * aii;
         t += SEG_RHO0 + SEG_RHO0;                                           // temp_mat.diagonal() += rho1 + rho2 (:785)
         d.td[i] = t;
@@ -178,6 +192,16 @@ __global__ void __launch_bounds__(T) seg_k_fix(SegDev d, int in, int out, int n_
         if (!d.live[i]) continue;
         if (n_live_new == 0) continue;
         double tmp = 0, aii = 0.0;
+        if (d.dia) {
+            EllRow R;
+            ell_load(d, i, R);
+            aii = R.v[3];
+#pragma unroll
+            for (int k = 0; k < 7; k++) {
+                const int nfc = d.newfix[R.c[k]];
+                if (nfc) tmp += R.v[k] * (nfc == 2 ? 1.0 : 0.0);             // a slot without an entry adds -0.0: no change
+            }
+        } else
         for (int k = 0; k < d.rowlen[i]; k++) {
             const int c = d.ecol[(size_t)k * d.n + i];
             const double a = d.eval[(size_t)k * d.n + i];
@@ -683,18 +707,16 @@ __device__ __forceinline__ void seg_b_post(const SegDev &d, int in, int out) {
             if (xh) xh[i] = xi;                                               // x_iters column (:1113-1116)
             // A x and A round(x) in one pass over the row (compute_cost :568-572, A_ptr restricted to the live variables)
             double t1 = 0, t2 = 0;
-            const int len = d.rowlen[i];
             if (d.ell_w <= 8) {                                               // all loads of the row in flight together (cf. tm_row)
-                int c[8]; double a[8], xc[8];
+                EllRow Rr;
+                ell_load(d, i, Rr);
+                double xc[8];
 #pragma unroll
-                for (int k = 0; k < 8; k++) if (k < len) c[k] = d.ecol[(size_t)k * d.n + i];
+                for (int k = 0; k < 8; k++) xc[k] = x[Rr.c[k]];
 #pragma unroll
-                for (int k = 0; k < 8; k++) if (k < len) a[k] = d.eval[(size_t)k * d.n + i];
-#pragma unroll
-                for (int k = 0; k < 8; k++) if (k < len) xc[k] = x[c[k]];
-#pragma unroll
-                for (int k = 0; k < 8; k++) if (k < len) { t1 += a[k] * xc[k]; t2 += a[k] * (xc[k] >= 0.5 ? 1.0 : 0.0); }
+                for (int k = 0; k < 8; k++) if (k < Rr.len) { t1 += Rr.v[k] * xc[k]; t2 += Rr.v[k] * (xc[k] >= 0.5 ? 1.0 : 0.0); }
             } else {
+                const int len = d.rowlen[i];
                 for (int k = 0; k < len; k++) {
                     const int c = d.ecol[(size_t)k * d.n + i];
                     const double xc = x[c], a = d.eval[(size_t)k * d.n + i];

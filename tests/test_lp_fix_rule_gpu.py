@@ -61,11 +61,8 @@ def test_reinit_resets_the_persistence_memory():
     a = _solver(I)
     a.solve_iter_fix(0, 300, min_fix=10)
     assert a.get_n() < I["n"]
-    a.set_problem(I["n"], I["l"], I["colptr"], I["rowidx"], I["b"])     # same size: the stale vector would have fitted
-    a.solve_init()
+    a.solve_init()                                                       # same size: the stale vector would have fitted
     b = _solver(I)
-    for s in (a, b):
-        s.solve_init()                                                   # re-init alone must reset as well
     ra, rb = a.solve_iter_fix(0, 300, min_fix=10), b.solve_iter_fix(0, 300, min_fix=10)
     assert ra == rb and a.get_n() == b.get_n()
     assert bits_equal(a.get_final_x_sol(), b.get_final_x_sol()) and a.cal_Obj() == b.cal_Obj()

@@ -142,6 +142,58 @@ def test_batched_legacy_solves_equal_individual_solves():
     assert batch[1].solve_iter() == ref[1][0]
 
 
+def test_diagonal_and_ell_storage_give_the_same_bits(monkeypatch):
+    """Image problems are held as 7 diagonals with u8 weights (SegDev::dia); LPBOX_SEG_NODIA keeps the ELL form with f64 values and i32
+    columns.  Same rows, same ascending-column order: a full legacy solve and an early-fixing run must agree bit for bit -- and a generic
+    matrix that is not of that shape (a value that is no small negative integer) must stay in ELL and still match the oracle."""
+    def run(image, nodes):
+        from lpbox_hip.seg import PyLPboxADMMsolver, load_gray
+        g = PyLPboxADMMsolver(0, nodes, 0)
+        g.write_files = False
+        g.set_image(load_gray(os.path.join(GOLDEN, "seg", image)))
+        g.solve_init()
+        vec, num, xs = np.zeros(g.get_org_n()), 0, []
+        for w in range(12):
+            if g.solve_iter_l2f(w * 10, (w + 1) * 10, vec, num):
+                break
+            xs.append(g.get_x_iters_2d(10).copy())
+            vec, num = scripted_fix_vec(xs[-1], last=5)
+            num = num if num > 10 else 0
+        l2f = (xs, g.get_obj(), g.counters(), g.get_x_sol().copy())
+        g.solve_init()
+        return g.debug_scalar("matrix_as_diagonals"), l2f, (g.solve_iter(), g.get_obj(), g.counters(), g.debug_vec("x"))
+    da, l2f_a, leg_a = run("7.jpg", 10000)
+    monkeypatch.setenv("LPBOX_SEG_NODIA", "1")
+    db, l2f_b, leg_b = run("7.jpg", 10000)
+    monkeypatch.delenv("LPBOX_SEG_NODIA")
+    assert (da, db) == (1.0, 0.0)
+    assert len(l2f_a[0]) == len(l2f_b[0]) and all(bits_equal(p, q) for p, q in zip(l2f_a[0], l2f_b[0]))
+    assert l2f_a[1:3] == l2f_b[1:3] and np.array_equal(l2f_a[3], l2f_b[3])
+    assert leg_a[:3] == leg_b[:3] and bits_equal(leg_a[3], leg_b[3])
+    # not diagonal-shaped: one off-diagonal value made fractional (symmetrically)
+    from lpbox_hip.seg import PyLPboxADMMsolver, load_gray
+    g0 = PyLPboxADMMsolver(0, 2500, 0)
+    g0.set_image(load_gray(os.path.join(GOLDEN, "seg", "7.jpg")))
+    P = g0.get_problem()
+    vals = P["vals"].copy()
+    r = 100
+    k = [q for q in range(P["rowptr"][r], P["rowptr"][r + 1]) if P["colidx"][q] == r + 1][0]
+    k2 = [q for q in range(P["rowptr"][r + 1], P["rowptr"][r + 2]) if P["colidx"][q] == r][0]
+    vals[k] = vals[k2] = -0.5
+    P2 = dict(P, vals=vals)
+    g = PyLPboxADMMsolver(0, 2500, 0)
+    g.write_files = False
+    g.set_problem(P2)
+    g.solve_init()
+    assert g.debug_scalar("matrix_as_diagonals") == 0.0
+    cfg = g.config()
+    o = O.SegOracle(0, 2500, 0, order=O.ORDER_GPU, T=cfg["threads"], chunk=cfg["threads"] * cfg["elems_per_thread"])
+    o.set_problem(P2)
+    o.solve_init()
+    assert g.solve_iter() == o.solve_iter() and g.counters() == (o.total_outer_iters, o.total_pcg_iters)
+    compare_state(g, o, "ELL, generic matrix")
+
+
 def test_batch_refuses_a_handle_listed_twice_and_leaves_the_solvers_usable():
     from lpbox_hip.lp import LpboxError
     from lpbox_hip.seg import PyLPboxADMMsolver, load_gray, solve_batch
