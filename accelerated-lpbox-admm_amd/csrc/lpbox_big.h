@@ -18,6 +18,12 @@
 
 #define BIG_T 256
 #define BIG_NPART 8
+#define BIG_MAXW 16        // ranks whose workgroup counts fit the descriptor (folded reductions; more ranks use the reduction launch)
+#define BIG_FOLD_U 4       // folded reductions: at most this many workgroup partials per thread (G <= BIG_FOLD_U * BIG_T)
+// Workgroup partials are kept per PHASE of the chain (a kernel that consumes the partials of one phase while it produces those of the
+// next must not overwrite what a slower workgroup still has to read): A prep -> y, B resid -> rows(first), C pcg_cols -> pcg_upd,
+// D pcg_upd -> rows / post, E post -> prep; X = the rare passes (init, fix), always reduced by big_k_fin.
+enum { BIG_PH_A = 0, BIG_PH_B, BIG_PH_C, BIG_PH_D, BIG_PH_E, BIG_PH_X, BIG_PH_COUNT };
 
 enum { BIG_HALT_NONE = 0, BIG_HALT_STOP = 1, BIG_HALT_WINDOW = 2, BIG_HALT_PCG_MORE = 3 };
 
@@ -49,8 +55,15 @@ struct BigDev {
     uint8_t *live;                        // 1 live, 0 fixed (x holds the fixed value)
     const uint8_t *newfix;                // this call's fix request: 0 none, 1 -> 0.0, 2 -> 1.0
     double *xhist; int ws_cap;            // x_iters staging [ws_cap][n_loc]
-    double *part;                         // [BIG_NPART][G] workgroup partials
-    double *red;                          // [BIG_NPART] reduced scalars (all-reduced over the ranks)
+    double *part;                         // [BIG_PH_COUNT][BIG_NPART][Gs] workgroup partials (Gs = partial stride, the same on every rank)
+    double *red;                          // [BIG_PH_COUNT][BIG_NPART] reduced scalars of each phase (all-reduced over the ranks) -- the route
+                                          // with a reduction launch.  Per phase: a chain that halts inside the PCG still runs the launches
+                                          // enqueued behind it, and the resumed PCG needs the totals it halted on
+    // FOLDED reductions (G <= BIG_FOLD_U * BIG_T): no reduction launch -- every consumer workgroup adds up the workgroup partials itself
+    // (same two-level tree, same bits); with W > 1 ranks the partials of all ranks are all-gathered into gpart[phase][rank][nv][Gs]
+    // and every consumer runs rank r's tree over its Gr[r] partials, then adds the W totals in rank order (what big_k_rank_sum did).
+    int fold, W, gathered, Gs, Gr[BIG_MAXW];      // gathered: the consumers read gpart (W > 1, or an RCCL communicator of one rank)
+    const double *gpart;
     BigState *st;                         // st[0], st[1]
 };
 
@@ -63,7 +76,7 @@ hipError_t big_launch_fix2(const BigDev &d, int *parity, hipStream_t s);        
 hipError_t big_launch_fix3(const BigDev &d, long n_live_new, double c1_new, int *parity, hipStream_t s);   // state + update_expression (:1329)
 hipError_t big_launch_pack_xiters(const BigDev &d, const int *live_idx, int rows, int ws, double *out, hipStream_t s);
 hipError_t big_launch_prep(const BigDev &d, int do_prep, int *parity, hipStream_t s);
-hipError_t big_launch_fin(const BigDev &d, int nv, hipStream_t s);                    // partials -> red[0..nv)
+hipError_t big_launch_fin(const BigDev &d, int nv, int phase, hipStream_t s);         // partials of a phase -> red[0..nv)
 hipError_t big_launch_y(const BigDev &d, int *parity, hipStream_t s);                 // y1, y2, refresh, rhs base, y3 (all rows)
 hipError_t big_launch_rhs_cols(const BigDev &d, int *parity, hipStream_t s);          // rhs += r4Et E^T(f-y3) - E^T z4
 hipError_t big_launch_rows(const BigDev &d, int mode, int *parity, hipStream_t s);    // q = E[:,shard] * v  (mode 0: gsrc, 1: PCG p)

@@ -81,6 +81,8 @@ struct lpbox_big {
     long long graph_launches = 0, graph_collectives = 0;       // of ONE replay (measured while capturing)
     bool use_graph = true;
     int G = 0, Gl = 0, EPT = 2, EPTl = 2, P = 1, Glr = 0, kmax = 28, parity = 0;
+    bool fold = false; int Gs = 0, Gr[BIG_MAXW] = {0};        // folded reductions (BigDev::fold): partial stride, workgroups of every rank
+    Buf<double> gpart;                                          // W > 1, folded: the gathered partials [phase][rank][nv][Gs]
     bool adaptive = true;
     int kmargin = 1;                                            // spare PCG launch groups beyond the largest count of the previous batch (LPBOX_BIG_KMARGIN)
     double kernel_ms = 0.0; long long launches = 0, collectives = 0;
@@ -104,6 +106,8 @@ struct lpbox_big {
         d.r = r.p; d.z = z.p; d.tmp = tmp.p; d.p0 = p0.p; d.p1 = p1.p; d.gsrc = gsrc.p;
         d.zp = zp.p; d.xt = xt.p; d.live = live.p; d.newfix = newfix.p; d.xhist = xhist.p; d.ws_cap = ws_cap;
         d.y3 = y3.p; d.z4 = z4.p; d.f = df.p; d.fz = fz.p; d.Ex = Ex.p; d.q = q.p; d.part = part.p; d.red = red.p; d.st = st.p;
+        d.fold = fold ? 1 : 0; d.W = world; d.Gs = Gs; d.gpart = gpart.p; d.gathered = gpart.p != nullptr;
+        for (int r = 0; r < BIG_MAXW; r++) d.Gr[r] = Gr[r];
         return d;
     }
 };
@@ -167,23 +171,40 @@ int agree_ok(lpbox_big *h, bool ok_here) {
 }
 
 #define CHK(expr) do { int rc_ = (expr); if (rc_ < 0) return rc_; } while (0)
-#define FIN(nv) do { HIPCHK(big_launch_fin(d, nv, h->stream)); h->launches++; CHK(allreduce(h, d.red, nv)); } while (0)
+// the totals of a phase's workgroup partials for its consumers.  Folded route: the consumers add them up themselves; only W > 1 ranks
+// have something to do here -- ONE all-gather of the partials (nv * Gs doubles per rank), no reduction launch, no rank-sum launch.
+// Other route: the reduction launch leaves them in red[], all-reduced over the ranks in rank order.
+int gather_partials(lpbox_big *h, const BigDev &d, int phase, int nv) {
+    const size_t PS = (size_t)BIG_NPART * h->Gs;
+    double *src = h->part.p + (size_t)phase * PS, *dst = h->gpart.p + (size_t)phase * h->world * PS;
+    const long count = (long)nv * h->Gs;
+    if (h->comm) NCCLCHK(g_rccl.AllGather(src, dst, (size_t)count, ncclDouble, h->comm, h->stream));
+    else if (h->ag) {
+        const int rc = h->ag(src, count, dst, h->ag_user);
+        if (rc != 0) return lpbox_fail(LPBOX_E_HIP, "all-gather callback failed (%d)", rc);
+    } else return lpbox_fail(LPBOX_E_STATE, "world = %d but neither an RCCL communicator nor an all-gather callback was set", h->world);
+    h->collectives++;
+    return LPBOX_OK;
+}
+#define FIN(nv, phase) do { if (h->fold) { if (h->gpart.p) CHK(gather_partials(h, d, phase, nv)); } \
+                            else { HIPCHK(big_launch_fin(d, nv, phase, h->stream)); h->launches++; CHK(allreduce(h, d.red + (phase) * BIG_NPART, nv)); } } while (0)
+#define FINX(nv) do { HIPCHK(big_launch_fin(d, nv, BIG_PH_X, h->stream)); h->launches++; CHK(allreduce(h, d.red + BIG_PH_X * BIG_NPART, nv)); } while (0)
 #define ROWS(mode) do { HIPCHK(big_launch_rows(d, mode, &h->parity, h->stream)); h->launches++; CHK(allreduce(h, d.q, h->l)); } while (0)
 
 int enqueue_pcg(lpbox_big *h, const BigDev &d, int pairs) {
     for (int k = 0; k < pairs; k++) {
         ROWS(1);
         HIPCHK(big_launch_pcg_cols(d, &h->parity, h->stream)); h->launches++;
-        FIN(1);
+        FIN(1, BIG_PH_C);
         HIPCHK(big_launch_pcg_upd(d, &h->parity, h->stream)); h->launches++;
-        FIN(2);
+        FIN(2, BIG_PH_D);
     }
     return LPBOX_OK;
 }
 
 int enqueue_tail(lpbox_big *h, const BigDev &d) {
     HIPCHK(big_launch_post(d, &h->parity, h->stream)); h->launches++;
-    FIN(5);
+    FIN(5, BIG_PH_E);
     ROWS(0);
     HIPCHK(big_launch_z4(d, 0, &h->parity, h->stream)); h->launches++;
     return LPBOX_OK;
@@ -191,12 +212,12 @@ int enqueue_tail(lpbox_big *h, const BigDev &d) {
 
 int enqueue_iteration(lpbox_big *h, const BigDev &d) {
     HIPCHK(big_launch_prep(d, 1, &h->parity, h->stream)); h->launches++;
-    FIN(1);
+    FIN(1, BIG_PH_A);
     HIPCHK(big_launch_y(d, &h->parity, h->stream)); h->launches++;
     HIPCHK(big_launch_rhs_cols(d, &h->parity, h->stream)); h->launches++;
     ROWS(0);
     HIPCHK(big_launch_resid(d, &h->parity, h->stream)); h->launches++;
-    FIN(3);
+    FIN(3, BIG_PH_B);
     CHK(enqueue_pcg(h, d, h->kmax));
     return enqueue_tail(h, d);
 }
@@ -257,7 +278,7 @@ void lpbox_big_destroy(lpbox_big_t *h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->d_rptr.release(); h->d_rcol.release(); h->d_cptr.release(); h->d_crow.release();
     for (Buf<double> *bp : {&h->x, &h->y1, &h->y2, &h->z1, &h->z2, &h->db, &h->pd, &h->dinv, &h->rhs, &h->r, &h->z, &h->tmp, &h->p0, &h->p1,
-                            &h->gsrc, &h->y3, &h->z4, &h->df, &h->Ex, &h->q, &h->part, &h->red, &h->xt, &h->xhist, &h->xi_out, &h->gath, &h->flag})
+                            &h->gsrc, &h->y3, &h->z4, &h->df, &h->Ex, &h->q, &h->part, &h->red, &h->xt, &h->xhist, &h->xi_out, &h->gath, &h->flag, &h->gpart})
         bp->release();
     for (auto &kv : h->gexec) (void)hipGraphExecDestroy(kv.second);
     for (hipGraph_t g : h->graphs) (void)hipGraphDestroy(g);
@@ -359,12 +380,37 @@ int lpbox_big_init(lpbox_big_t *h) {
     CHK(use_device(h));
     if (!h->uploaded) {
         const int n = h->n_loc, l = h->l;
-        h->EPT = 2; while ((n + BIG_T * h->EPT - 1) / (BIG_T * h->EPT) > 2 * BIG_T * 8 && h->EPT < 64) h->EPT *= 2;
-        h->G = (n + BIG_T * h->EPT - 1) / (BIG_T * h->EPT);
+        if (!h->stream) { HIPCHK(hipStreamCreate(&h->stream)); h->own_stream = true; }
+        HIPCHK(h->flag.alloc(64));
+        h->q_cap = (long)h->world * (((long)l + h->world - 1) / h->world);           // whole row blocks for the exchange
+        if (h->comm) HIPCHK(h->gath.alloc((size_t)std::max<long>(h->q_cap, 64L * h->world)));          // W row blocks, or W scalar groups
+        else if (h->ag) HIPCHK(h->gath.alloc((size_t)h->world * (size_t)std::max(l, 64)));              // W whole contributions
+        // every rank learns the shard sizes of all ranks: the slots per thread (hence the partial stride) must be the same everywhere
+        std::vector<double> nloc_all((size_t)std::max(h->world, 1), 0.0);
+        nloc_all[h->rank] = (double)n;
+        if (h->world > 1 && h->world <= 64) {
+            HIPCHK(hipMemcpyAsync(h->flag.p, nloc_all.data(), sizeof(double) * (size_t)h->world, hipMemcpyHostToDevice, h->stream));
+            CHK(allreduce(h, h->flag.p, h->world));
+            HIPCHK(hipMemcpyAsync(nloc_all.data(), h->flag.p, sizeof(double) * (size_t)h->world, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+        }
+        long nmax = n;
+        for (double v : nloc_all) nmax = std::max(nmax, (long)v);
+        // slots per thread: as few as keep the workgroup partials within reach of the folded reductions (G <= BIG_FOLD_U * BIG_T: the
+        // consumers add them up themselves, no reduction launch; 10^6 variables on one rank: 4 slots, 977 workgroups), beyond that the
+        // reduction launch with at most 4096 partials
+        const int fold_cap = BIG_FOLD_U * BIG_T;
+        auto groups = [](long nn, int ept) { return (int)((nn + (long)BIG_T * ept - 1) / ((long)BIG_T * ept)); };
+        h->EPT = 2; while (groups(nmax, h->EPT) > fold_cap && h->EPT < 8) h->EPT *= 2;
+        if (groups(nmax, h->EPT) > fold_cap) { h->EPT = 2; while (groups(nmax, h->EPT) > 2 * BIG_T * 8 && h->EPT < 64) h->EPT *= 2; }
+        if (const char *e = getenv("LPBOX_BIG_EPT")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) h->EPT = std::max(v, h->EPT); }   // tuning
+        h->G = groups(n, h->EPT);
+        h->Gs = std::max(groups(nmax, h->EPT), 1);
+        h->fold = h->Gs <= fold_cap && h->world <= BIG_MAXW && getenv("LPBOX_BIG_NOFOLD") == nullptr;   // LPBOX_BIG_NOFOLD: keep the reduction launches (A/B)
+        for (int r = 0; r < BIG_MAXW; r++) h->Gr[r] = r < h->world ? groups((long)nloc_all[r], h->EPT) : 0;
         h->EPTl = 2; h->Gl = (l + BIG_T * h->EPTl - 1) / (BIG_T * h->EPTl);
         h->Glr = (l + BIG_T - 1) / BIG_T;
         if (const char *e = getenv("LPBOX_BIG_KMARGIN")) h->kmargin = std::max(0, atoi(e));
-        if (!h->stream) { HIPCHK(hipStreamCreate(&h->stream)); h->own_stream = true; }
         HIPCHK(hipEventCreate(&h->ev0)); HIPCHK(hipEventCreate(&h->ev1));
         HIPCHK(h->d_rptr.alloc((size_t)h->P * l + 1)); HIPCHK(h->d_rcol.alloc(h->nnz)); HIPCHK(h->d_cptr.alloc((size_t)n + 1)); HIPCHK(h->d_crow.alloc(h->nnz));
         for (Buf<double> *bp : {&h->x, &h->y1, &h->y2, &h->z1, &h->z2, &h->db, &h->pd, &h->dinv, &h->rhs, &h->r, &h->z, &h->tmp, &h->p0, &h->p1, &h->gsrc, &h->xt})
@@ -373,19 +419,19 @@ int lpbox_big_init(lpbox_big_t *h) {
         HIPCHK(hipMemset(h->newfix.p, 0, (size_t)n));
         for (Buf<double> *bp : {&h->y3, &h->z4, &h->df, &h->Ex}) HIPCHK(bp->alloc(l));
         HIPCHK(h->fz.alloc(l));
-        h->q_cap = (long)h->world * (((long)l + h->world - 1) / h->world);           // whole row blocks for the exchange
         HIPCHK(h->q.alloc((size_t)h->q_cap)); HIPCHK(hipMemset(h->q.p, 0, sizeof(double) * (size_t)h->q_cap));
-        if (h->comm) HIPCHK(h->gath.alloc((size_t)std::max<long>(h->q_cap, 64L * h->world)));          // W row blocks, or W scalar groups
-        else if (h->ag) HIPCHK(h->gath.alloc((size_t)h->world * (size_t)std::max(l, 64)));              // W whole contributions
-        HIPCHK(h->flag.alloc(8));
-        HIPCHK(h->part.alloc((size_t)BIG_NPART * h->G)); HIPCHK(h->red.alloc(BIG_NPART)); HIPCHK(h->st.alloc(2));
+        HIPCHK(h->part.alloc((size_t)BIG_PH_COUNT * BIG_NPART * h->Gs)); HIPCHK(h->red.alloc(BIG_PH_COUNT * BIG_NPART)); HIPCHK(h->st.alloc(2));
+        if (h->fold && (h->world > 1 || h->comm)) {         // (a one-rank RCCL communicator runs the exchange against itself: tests)
+            HIPCHK(h->gpart.alloc((size_t)BIG_PH_COUNT * h->world * BIG_NPART * h->Gs));
+            HIPCHK(hipMemset(h->gpart.p, 0, sizeof(double) * (size_t)BIG_PH_COUNT * h->world * BIG_NPART * h->Gs));
+        }
         HIPCHK(hipMemcpy(h->d_rptr.p, h->rptr.data(), sizeof(int) * ((size_t)h->P * l + 1), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d_rcol.p, h->rcol.data(), sizeof(int) * (size_t)h->nnz, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d_cptr.p, h->cptr.data(), sizeof(int) * ((size_t)n + 1), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d_crow.p, h->crow.data(), sizeof(int) * (size_t)h->nnz, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->db.p, h->b.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
-        HIPCHK(hipMemset(h->part.p, 0, sizeof(double) * (size_t)BIG_NPART * h->G));
-        HIPCHK(hipMemset(h->red.p, 0, sizeof(double) * BIG_NPART));
+        HIPCHK(hipMemset(h->part.p, 0, sizeof(double) * (size_t)BIG_PH_COUNT * BIG_NPART * h->Gs));
+        HIPCHK(hipMemset(h->red.p, 0, sizeof(double) * BIG_PH_COUNT * BIG_NPART));
         h->uploaded = true;
     }
     HIPCHK(hipMemcpyAsync(h->df.p, h->f.data(), sizeof(double) * (size_t)h->l, hipMemcpyHostToDevice, h->stream));
@@ -395,7 +441,7 @@ int lpbox_big_init(lpbox_big_t *h) {
     const BigDev d = h->dev();
     h->parity = 0;
     HIPCHK(big_launch_init(d, std::pow((double)h->n_glob, 1.0 / 2), h->stream));   // pow(n, 1/p), p = 2 (LPcpp:427,503), n = ALL variables
-    CHK(allreduce(h, d.red, 1));
+    CHK(allreduce(h, d.red + BIG_PH_X * BIG_NPART, 1));
     HIPCHK(big_launch_init2(d, h->stream));
     ROWS(0);                                                                        // E * x0 for the first y3 (:720)
     HIPCHK(big_launch_z4(d, 1, &h->parity, h->stream));
@@ -498,10 +544,10 @@ int lpbox_big_iterate_l2f(lpbox_big_t *h, int iter_start, int iter_end, const do
         const long n_live_new = h->n_live_glob - num_global;
         HIPCHK(hipMemcpyAsync(h->newfix.p, nf.data(), nf.size(), hipMemcpyHostToDevice, h->stream));
         HIPCHK(big_launch_fix1(d, h->stream)); h->launches++;
-        FIN(1);                                                                     // fix_obj = b2.x2
+        FINX(1);                                                                    // fix_obj = b2.x2
         ROWS(0);                                                                    // q = E2 * x2
         HIPCHK(big_launch_fix2(d, &h->parity, h->stream)); h->launches++;
-        FIN(1);                                                                     // |x_live|^2
+        FINX(1);                                                                    // |x_live|^2
         HIPCHK(big_launch_fix3(d, n_live_new, std::pow((double)n_live_new, 1.0 / 2), &h->parity, h->stream)); h->launches++;
         if (n_live_new != 0) {
             ROWS(0);                                                                // E * x (live columns) for the first y3
@@ -628,7 +674,7 @@ int lpbox_big_get_scalar(lpbox_big_t *h, const char *name, double *out) {
         {"sum_fix_obj", s.sum_fix_obj}, {"fix_obj", s.fix_obj}, {"c1", s.c1}, {"ret", (double)s.ret}, {"n_live", (double)h->n_live_glob},
         {"stop", (double)s.stop}, {"plain_iter_p1", (double)s.plain_iter_p1}, {"kmax", (double)h->kmax},
         {"launches", (double)h->launches}, {"collectives", (double)h->collectives}, {"kernel_ms", h->kernel_ms},
-        {"threads", (double)BIG_T}, {"chunk", (double)(BIG_T * h->EPT)}, {"groups", (double)h->G}, {"row_slices", (double)h->P},
+        {"threads", (double)BIG_T}, {"chunk", (double)(BIG_T * h->EPT)}, {"groups", (double)h->G}, {"row_slices", (double)h->P}, {"folded_reductions", h->fold ? 1.0 : 0.0},
     };
     for (auto &e : tab) if (!strcmp(e.n, name)) { *out = e.v; return LPBOX_OK; }
     return lpbox_fail(LPBOX_E_BADARG, "unknown scalar '%s'", name);

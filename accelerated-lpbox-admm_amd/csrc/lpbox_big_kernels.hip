@@ -36,20 +36,59 @@ __device__ __forceinline__ void forward_state(const BigDev &d, int in, int out) 
 // workgroup that arrives last (ticket counter, __threadfence before and after) reduces them inside the producing kernel -- 41
 // launches per iteration fewer, but 3.05 instead of 1.52 ms per iteration at n = 1e6: a device-scope fence per workgroup writes the
 // XCD's L2 back each time.  Dropped.
+__device__ __forceinline__ double *part_ptr(const BigDev &d, int phase) { return d.part + (size_t)phase * BIG_NPART * d.Gs; }
+
 template <int NV>
-__device__ __forceinline__ void store_partials(const BigDev &d, double (&v)[NV], double *red, int &parity) {
+__device__ __forceinline__ void store_partials(const BigDev &d, int phase, double (&v)[NV], double *red, int &parity) {
     block_sum<T, NV>(v, red, parity);
     if (threadIdx.x == 0) {
+        double *pp = part_ptr(d, phase);
 #pragma unroll
-        for (int k = 0; k < NV; k++) d.part[(size_t)k * d.G + blockIdx.x] = v[k];
+        for (int k = 0; k < NV; k++) pp[(size_t)k * d.Gs + blockIdx.x] = v[k];
     }
 }
 
 // red[v] = tree over the G workgroup partials of value v (second level of the fixed reduction order)
-__global__ void __launch_bounds__(T) big_k_fin(BigDev d, int nv) {
+__global__ void __launch_bounds__(T) big_k_fin(BigDev d, int nv, int phase) {
     __shared__ double red[2 * RED_MAXV * RED_MAXW];
     int parity = 0;
-    fin_reduce<T>(d.part, d.G, nv, d.red, red, parity);
+    fin_reduce<T>(part_ptr(d, phase), d.G, nv, d.red + phase * BIG_NPART, red, parity, d.Gs);
+}
+
+// The totals of the first NV of the NVP values a phase holds, for every thread of the calling workgroup (a uniform call: it contains
+// barriers).  Route with a reduction launch: big_k_fin (+ the cross-rank sum) has left them in d.red.  Folded route: this workgroup
+// adds the partials up itself -- per rank the order of big_k_fin (thread t: partials t, t + T, ... ascending, then the block tree),
+// the rank totals in rank order like big_k_rank_sum -- so both routes give the same bits.  All loads of a rank are issued before
+// the first addition.
+template <int NV, int NVP>
+__device__ __forceinline__ void get_red(const BigDev &d, int phase, double (&out)[NV], double *red, int &parity) {
+    static_assert(NV <= NVP, "a phase holds NVP values");
+    if (!d.fold) {
+#pragma unroll
+        for (int k = 0; k < NV; k++) out[k] = d.red[phase * BIG_NPART + k];
+        return;
+    }
+    const int W = d.gathered ? d.W : 1;
+    for (int r = 0; r < W; r++) {
+        const double *base = d.gathered ? d.gpart + ((size_t)phase * W * BIG_NPART + (size_t)r * NVP) * d.Gs : part_ptr(d, phase);
+        const int G = d.gathered ? d.Gr[r] : d.G;
+        double t[NV][BIG_FOLD_U];
+#pragma unroll
+        for (int k = 0; k < NV; k++)
+#pragma unroll
+            for (int u = 0; u < BIG_FOLD_U; u++) { const int e = threadIdx.x + u * T; t[k][u] = e < G ? base[(size_t)k * d.Gs + e] : 0.0; }
+        double a[NV];
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int u = 0; u < BIG_FOLD_U; u++) acc = (int)threadIdx.x + u * T < G ? acc + t[k][u] : acc;
+            a[k] = acc;
+        }
+        block_sum<T, NV>(a, red, parity);
+#pragma unroll
+        for (int k = 0; k < NV; k++) out[k] = r == 0 ? a[k] : out[k] + a[k];
+    }
 }
 
 __global__ void __launch_bounds__(T) big_k_init(BigDev d, double c1) {          // ADMM_lp_iters_init LPcpp:489-763
@@ -67,7 +106,7 @@ __global__ void __launch_bounds__(T) big_k_init(BigDev d, double c1) {          
         }
         pb[0] = pb[0] + c;
     }
-    if (blockIdx.x < d.G) store_partials<1>(d, pb, red, parity);
+    if (blockIdx.x < d.G) store_partials<1>(d, BIG_PH_X, pb, red, parity);
     for (int s = 0; s < d.EPTl; s++) {
         const int i = blockIdx.x * (T * d.EPTl) + s * T + threadIdx.x;
         if (i < d.l) { d.z4[i] = 0.0; d.y3[i] = 0.0; d.fz[i] = make_double2(0.0, 0.0); d.Ex[i] = 0.0; }   // :650
@@ -83,8 +122,8 @@ __global__ void __launch_bounds__(T) big_k_init(BigDev d, double c1) {          
 }
 
 __global__ void big_k_init2(BigDev d) {       // after the partial of b.x0 has been reduced: best_bin_obj (:727)
-    d.st[0].best_bin_obj = d.red[0];
-    d.st[1].best_bin_obj = d.red[0];
+    d.st[0].best_bin_obj = d.red[BIG_PH_X * BIG_NPART];
+    d.st[1].best_bin_obj = d.red[BIG_PH_X * BIG_NPART];
 }
 
 __global__ void big_k_set_window(BigDev d, int in, int out, int iter_start, int iter_end, int l2f) {
@@ -111,14 +150,16 @@ __global__ void __launch_bounds__(T) big_k_prep(BigDev d, int in, int out, int d
     if (fin && (it + 1) % LP_RHO_STEP == 0) rho2 = LP_LEARNING_FACT * rho2;
     const int next_iter = fin ? it + 1 : it;
     const bool will_prep = do_prep && !halt0 && next_iter < iter_end;
+    double e5[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    if (blockIdx.x == 0 && fin) get_red<5, 5>(d, BIG_PH_E, e5, red, parity);    // uniform over workgroup 0
     if (LEADER) {
         d.st[out] = *si;
         BigState *s = d.st + out;
         if (fin) {
             s->have_prev = 0;
-            const double xn = sqrt(d.red[0]);
+            const double xn = sqrt(e5[0]);
             const double t0 = (xn < 2.2204e-16) ? 2.2204e-16 : xn;
-            s->cvg1 = sqrt(d.red[1]) / t0; s->cvg2 = sqrt(d.red[2]) / t0;      // :931-933
+            s->cvg1 = sqrt(e5[1]) / t0; s->cvg2 = sqrt(e5[2]) / t0;            // :931-933
             bool stopped = false;
             if (s->cvg1 <= LP_STOP_THRESHOLD && s->cvg2 <= LP_STOP_THRESHOLD && (s->l2f || it != s->iter_start)) {   // :934 / :1503
                 if (s->l2f) s->ret = 1;                                          // :1505 (plain loop: ret stays 0)
@@ -131,7 +172,7 @@ __global__ void __launch_bounds__(T) big_k_prep(BigDev d, int in, int out, int d
                     s->gamma_val = g < 1.0 ? 1.0 : g;
                     s->rhoUpdated = 1; s->rcr = LP_LEARNING_FACT - 1.0;
                 }
-                s->obj_val = d.red[3];                                            // :972
+                s->obj_val = e5[3];                                               // :972
                 int hn = s->hist_n;
                 if (hn < LP_HIST) s->hist[hn] = s->obj_val;
                 else { for (int k = 0; k < LP_HIST - 1; k++) s->hist[k] = s->hist[k + 1]; s->hist[LP_HIST - 1] = s->obj_val; }
@@ -149,7 +190,7 @@ __global__ void __launch_bounds__(T) big_k_prep(BigDev d, int in, int out, int d
                 }
                 if (s->std_obj <= LP_STD_THRESHOLD) { s->ret = 1; s->stop = LP_STOP_OBJSTD; stopped = true; }   // :977
                 else {
-                    s->cur_obj = d.red[4];                                        // :1001-1003
+                    s->cur_obj = e5[4];                                           // :1001-1003
                     if (s->best_bin_obj >= s->cur_obj) s->best_bin_obj = s->cur_obj;
                 }
             }
@@ -167,11 +208,13 @@ __global__ void __launch_bounds__(T) big_k_prep(BigDev d, int in, int out, int d
         if (j < d.n_loc && d.live[j]) { const double u = (d.x[j] + d.z2[j] / rho2) - 0.5; c = u * u; }
         pa[0] = pa[0] + c;
     }
-    store_partials<1>(d, pa, red, parity);
+    store_partials<1>(d, BIG_PH_A, pa, red, parity);
 }
 
 // y1, y2, expression refresh (:831-866), rhs base, PCG start x0 = y1; for the rows: y3 = max(0, f - Ex - z4/rho4), fz = (f - y3, z4)
 __global__ void __launch_bounds__(T) big_k_y(BigDev d, int in, int out) {
+    __shared__ double red[2 * RED_MAXV * RED_MAXW];
+    int parity = 0;
     const BigState *si = d.st + in;
     if (si->halt || si->phase != 1) { forward_state(d, in, out); return; }
     const double rho1 = si->rho1, rho2 = si->rho2, rho4 = si->rho4, c1 = si->c1;
@@ -181,7 +224,9 @@ __global__ void __launch_bounds__(T) big_k_y(BigDev d, int in, int out) {
     const double inc = si->rcr * (si->prev_rho1 + si->prev_rho2), inc4 = si->rcr * si->prev_rho4;
     if (first) { dI = 0.0; dI += rho1 + rho2; r4Et = rho4; }                     // update_expression(0) :2289-2404
     if (refresh) { dI += inc; r4Et = LP_LEARNING_FACT * r4Et; }                  // :851-866
-    const double c2 = 2 * sqrt(d.red[0]);
+    double a1[1];
+    get_red<1, 1>(d, BIG_PH_A, a1, red, parity);
+    const double c2 = 2 * sqrt(a1[0]);
     if (blockIdx.x < d.G)
         for (int q = 0; q < d.EPT; q++) {
             const int j = blockIdx.x * (T * d.EPT) + q * T + threadIdx.x;
@@ -299,6 +344,8 @@ __device__ __forceinline__ double row_sum_sliced(const BigDev &d, int i, const d
 }
 
 __global__ void __launch_bounds__(T) big_k_rows(BigDev d, int in, int out, int mode) {
+    __shared__ double red[2 * RED_MAXV * RED_MAXW];
+    int parity = 0;
     const BigState *si = d.st + in;
     if (si->halt) { forward_state(d, in, out); return; }
     double beta = 0.0;
@@ -311,18 +358,22 @@ __global__ void __launch_bounds__(T) big_k_rows(BigDev d, int in, int out, int m
         bool done = false; int zero_x = 0;
         first = k == 0;
         if (first) {
-            rhsNorm2 = d.red[0];
+            double b3[3];
+            get_red<3, 3>(d, BIG_PH_B, b3, red, parity);
+            rhsNorm2 = b3[0];
             if (rhsNorm2 == 0) { done = true; zero_x = 1; }                      // :273-278
             else {
                 double thr = LP_PCG_TOL * LP_PCG_TOL * rhsNorm2;                 // :281
                 if (thr < DBL_MIN) thr = DBL_MIN;
                 threshold = thr;
-                if (d.red[1] < thr) done = true;                                 // :284
-                absNew = d.red[2];
+                if (b3[1] < thr) done = true;                                    // :284
+                absNew = b3[2];
             }
         } else {
-            if (d.red[0] < threshold || k >= LP_PCG_MAXITERS) done = true;       // :309-312, :296
-            else { const double absOld = absNew; absNew = d.red[1]; beta = absNew / absOld; }   // :316-318
+            double d2[2];
+            get_red<2, 2>(d, BIG_PH_D, d2, red, parity);
+            if (d2[0] < threshold || k >= LP_PCG_MAXITERS) done = true;          // :309-312, :296
+            else { const double absOld = absNew; absNew = d2[1]; beta = absNew / absOld; }   // :316-318
         }
         if (LEADER) {
             d.st[out] = *si;
@@ -410,7 +461,7 @@ __global__ void __launch_bounds__(T) big_k_resid(BigDev d, int in, int out) {   
         }
         pb[0] = pb[0] + c0; pb[1] = pb[1] + c1; pb[2] = pb[2] + c2;
     }
-    store_partials<3>(d, pb, red, parity);
+    store_partials<3>(d, BIG_PH_B, pb, red, parity);
     if (LEADER) { d.st[out] = *si; d.st[out].pcg_k = 0; d.st[out].pcg_done = 0; d.st[out].pcg_first = 0; d.st[out].phase = 2; }
 }
 
@@ -455,7 +506,7 @@ __global__ void __launch_bounds__(T) big_k_pcg_cols(BigDev d, int in, int out) {
         }
         pc[0] = pc[0] + c;
     }
-    store_partials<1>(d, pc, red, parity);
+    store_partials<1>(d, BIG_PH_C, pc, red, parity);
     forward_state(d, in, out);
 }
 
@@ -465,7 +516,9 @@ __global__ void __launch_bounds__(T) big_k_pcg_upd(BigDev d, int in, int out) { 
     const BigState *si = d.st + in;
     if (si->halt || si->phase != 2 || si->pcg_done) { forward_state(d, in, out); return; }
     const int k = si->pcg_k;
-    const double alpha = si->absNew / d.red[0];
+    double c1v[1];
+    get_red<1, 1>(d, BIG_PH_C, c1v, red, parity);
+    const double alpha = si->absNew / c1v[0];
     // (alpha < 0 -> the plain loop ignores the PCG's -1 return, LPcpp:894; x keeps the updates made so far, which is what
     //  happens here too because the remaining pairs fall through once pcg_done is set)
     const bool fail = alpha < 0;
@@ -487,7 +540,7 @@ __global__ void __launch_bounds__(T) big_k_pcg_upd(BigDev d, int in, int out) { 
             }
             pd2[0] = pd2[0] + a; pd2[1] = pd2[1] + b2;
         }
-    if (!fail) store_partials<2>(d, pd2, red, parity);
+    if (!fail) store_partials<2>(d, BIG_PH_D, pd2, red, parity);
     if (LEADER) {
         d.st[out] = *si;
         if (fail) { d.st[out].pcg_done = 1; d.st[out].stop = LP_STOP_PCG; }
@@ -503,7 +556,9 @@ __global__ void __launch_bounds__(T) big_k_post(BigDev d, int in, int out) {
     if (si->halt || si->phase != 2) { forward_state(d, in, out); return; }
     const int k = si->pcg_k;
     if (!si->pcg_done) {                      // the exit test of the last update is still pending
-        if (!(k >= 1 && (d.red[0] < si->threshold || k >= LP_PCG_MAXITERS))) {
+        double d1[1] = {0.0};
+        if (k >= 1) get_red<1, 2>(d, BIG_PH_D, d1, red, parity);
+        if (!(k >= 1 && (d1[0] < si->threshold || k >= LP_PCG_MAXITERS))) {
             if (LEADER) { d.st[out] = *si; d.st[out].halt = BIG_HALT_PCG_MORE; }
             return;
         }
@@ -531,7 +586,7 @@ __global__ void __launch_bounds__(T) big_k_post(BigDev d, int in, int out) {
         }
         e5[0] = e5[0] + v0; e5[1] = e5[1] + v1; e5[2] = e5[2] + v2; e5[3] = e5[3] + v3; e5[4] = e5[4] + v4;
     }
-    store_partials<5>(d, e5, red, parity);
+    store_partials<5>(d, BIG_PH_E, e5, red, parity);
     if (LEADER) {
         d.st[out] = *si;
         BigState *s = d.st + out;
@@ -580,7 +635,7 @@ __global__ void __launch_bounds__(T) big_k_fix1(BigDev d) {          // x2 = the
         }
         pf[0] = pf[0] + c;
     }
-    store_partials<1>(d, pf, red, parity);
+    store_partials<1>(d, BIG_PH_X, pf, red, parity);
 }
 
 __global__ void __launch_bounds__(T) big_k_fix2(BigDev d, int in, int out) {   // red[0] = fix_obj, q = E2*x2 (all ranks)
@@ -591,7 +646,7 @@ __global__ void __launch_bounds__(T) big_k_fix2(BigDev d, int in, int out) {   /
             const int i = blockIdx.x * (T * d.EPTl) + s * T + threadIdx.x;
             if (i < d.l) d.f[i] = d.f[i] - d.q[i];                                  // f1 = f - E2*x2 (:1278)
         }
-    if (LEADER) { d.st[out] = d.st[in]; d.st[out].fix_obj = d.red[0]; }
+    if (LEADER) { d.st[out] = d.st[in]; d.st[out].fix_obj = d.red[BIG_PH_X * BIG_NPART]; }
     if (blockIdx.x >= d.G) return;
     double px[1] = {0.0};
     for (int q = 0; q < d.EPT; q++) {
@@ -604,7 +659,7 @@ __global__ void __launch_bounds__(T) big_k_fix2(BigDev d, int in, int out) {   /
         }
         px[0] = px[0] + c;
     }
-    store_partials<1>(d, px, red, parity);
+    store_partials<1>(d, BIG_PH_X, px, red, parity);
 }
 
 // red[0] = |x_live|^2.  n_live_new == 0: everything is fixed (:1212-1217, nothing else is updated).
@@ -617,7 +672,7 @@ __global__ void __launch_bounds__(T) big_k_fix3(BigDev d, int in, int out, long 
         s->n_live_lo = (int)(n_live_new & 0x7fffffff); s->n_live_hi = (int)(n_live_new >> 31);
         if (n_live_new == 0) { s->ret = 1; s->stop = LP_STOP_ALLFIXED; s->halt = BIG_HALT_STOP; }
         else {
-            if (sqrt(d.red[0]) < 1e-3) s->ret = 1;                                 // :1223
+            if (sqrt(d.red[BIG_PH_X * BIG_NPART]) < 1e-3) s->ret = 1;                                 // :1223
             s->prev_sum = s->sum_fix_obj; s->sum_fix_obj += s->fix_obj; s->prev_obj = s->cur_obj;   // :1247-1250
             s->c1 = c1_new;
             double dI = 0.0; dI += rho1 + rho2;                                      // update_expression (:1329 -> :2289-2404)
@@ -667,7 +722,7 @@ __global__ void big_k_pack_xiters(BigDev d, const int *live_idx, int rows, int w
 
 hipError_t big_launch_init(const BigDev &d, double c1, hipStream_t s) {
     hipLaunchKernelGGL(big_k_init, dim3(d.G > d.Gl ? d.G : d.Gl), dim3(T), 0, s, d, c1);
-    hipLaunchKernelGGL(big_k_fin, dim3(1), dim3(T), 0, s, d, 1);
+    hipLaunchKernelGGL(big_k_fin, dim3(1), dim3(T), 0, s, d, 1, BIG_PH_X);
     return hipGetLastError();
 }
 hipError_t big_launch_init2(const BigDev &d, hipStream_t s) {
@@ -704,8 +759,8 @@ hipError_t big_launch_resume(const BigDev &d, int reset_pcg_max, int *parity, hi
     return hipGetLastError();
 }
 hipError_t big_launch_prep(const BigDev &d, int do_prep, int *parity, hipStream_t s) { BIG_LAUNCH(big_k_prep, d.G, do_prep); return hipGetLastError(); }
-hipError_t big_launch_fin(const BigDev &d, int nv, hipStream_t s) {
-    hipLaunchKernelGGL(big_k_fin, dim3(1), dim3(T), 0, s, d, nv);
+hipError_t big_launch_fin(const BigDev &d, int nv, int phase, hipStream_t s) {
+    hipLaunchKernelGGL(big_k_fin, dim3(1), dim3(T), 0, s, d, nv, phase);
     return hipGetLastError();
 }
 hipError_t big_launch_y(const BigDev &d, int *parity, hipStream_t s) { BIG_LAUNCH(big_k_y, (d.G > d.Gl ? d.G : d.Gl)); return hipGetLastError(); }

@@ -162,6 +162,12 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double *red, int &par
         v[k] = t[k][0];
     }
 #endif
+#ifdef LPBOX_RED_NOSINK
+    // all totals exist HERE: without this the compiler sinks the partial loads + additions of a value that is only used behind a
+    // branch on another value (the PCG exit test) below that branch, i.e. a second LDS round trip on the critical path
+#pragma unroll
+    for (int k = 0; k < NV; k++) asm volatile("" : "+v"(v[k]));
+#endif
     parity ^= 1;
 }
 
@@ -171,11 +177,12 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double *red, int &par
 // addition -- one memory latency instead of one per partial (5.1 -> about 3 us per launch at G = 1954).
 constexpr int FIN_U = 16;
 template <int T>
-__device__ __forceinline__ void fin_reduce(const double *part, int G, int nv, double *out, double *red, int &parity) {
+__device__ __forceinline__ void fin_reduce(const double *part, int G, int nv, double *out, double *red, int &parity, int stride = 0) {
+    if (stride <= 0) stride = G;                 // partials of value v at part[v * stride ..]
     if (G > 2 * T && G <= T * FIN_U) {          // (with one or two partials per thread the plain loop below is the shorter program: A/B on the generic path)
         for (int v0 = 0; v0 < nv; v0 += 2) {
             const bool two = v0 + 1 < nv;
-            const double *pa = part + (size_t)v0 * G, *pb = part + (size_t)(two ? v0 + 1 : v0) * G;
+            const double *pa = part + (size_t)v0 * stride, *pb = part + (size_t)(two ? v0 + 1 : v0) * stride;
             double ta[FIN_U], tb[FIN_U];
 #pragma unroll
             for (int u = 0; u < FIN_U; u++) {
@@ -200,7 +207,7 @@ __device__ __forceinline__ void fin_reduce(const double *part, int G, int nv, do
         return;
     }
     for (int v = 0; v < nv; v++) {
-        const double *p = part + (size_t)v * G;
+        const double *p = part + (size_t)v * stride;
         double a[1] = {0.0};
         for (int e = threadIdx.x; e < G; e += T) a[0] = a[0] + p[e];
         block_sum<T, 1>(a, red, parity);

@@ -41,6 +41,15 @@ namespace {
 #define STAMP(k)
 #define STAMP_STORE
 #endif
+// -DLPBOX_STAMPS_PREBAR (with LPBOX_STAMPS): the two LDS hand-overs of a PCG iteration are stamped on BOTH sides of their barrier --
+// slot 12 = "p -> LDS" up to the barrier, 3 = waiting at it; 13 = "q -> LDS", 5 = waiting -- and the post-PCG phases F, G, H share slot 14
+#if defined(LPBOX_STAMPS) && defined(LPBOX_STAMPS_PREBAR)
+#define STAMP_PRE(k) STAMP(k)
+#define STAMP_POST(k) STAMP(14)
+#else
+#define STAMP_PRE(k)
+#define STAMP_POST(k) STAMP(k)
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // LDS carve-up shared by the launcher (size) and the kernel (pointers)
@@ -158,7 +167,10 @@ __device__ __forceinline__ void gather_all(const Lists<C> &g, const uint16_t *id
 #pragma unroll
     for (int s = 0; s < N; s++) acc[s] = 0.0;
     if constexpr (N == 1) {
-        constexpr int G1 = 2;                                          // granularity of the wave-uniform list length
+#ifndef LPBOX_LP_G1
+#define LPBOX_LP_G1 2
+#endif
+        constexpr int G1 = LPBOX_LP_G1;                                // granularity of the wave-uniform list length (a straight-line path per multiple)
         int nch_ = (g.wlen[0] + G1 - 1) / G1;
 #ifdef LPBOX_KO_COLCAP
         if (STRIDE == 24 && nch_ > LPBOX_KO_COLCAP) nch_ = LPBOX_KO_COLCAP;
@@ -886,6 +898,7 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
                     while (k_it < LP_PCG_MAXITERS) {                  // :296
 #pragma unroll
                         for (int s = 0; s < EPT; s++) gx[s * T + tid] = live[s] ? p[s] : 0.0;
+                        STAMP_PRE(12)
                         __syncthreads();
                         STAMP(3)
                         {
@@ -899,6 +912,7 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
 #pragma unroll
                             for (int s = 0; s < EPT; s++) if (rvalid(s)) gl[3 * rgl(s)] = q[s];
                         }
+                        STAMP_PRE(13)
                         __syncthreads();
                         STAMP(5)
                         double tmp[EPT];
@@ -1018,10 +1032,10 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
                 p5[3] = p5[3] + (live[s] ? b.get(s) * x[s] : 0.0);
                 p5[4] = p5[4] + (live[s] ? b.get(s) * xb : 0.0);
             }
-            STAMP(12)
+            STAMP_POST(12)
             block_sum<T, 6>(p5, red, parity);
             pnorm = p5[5];
-            STAMP(13)
+            STAMP_POST(13)
             {
                 const double xn = sqrt(p5[0]);
                 const double temp0 = (xn < 2.2204e-16) ? 2.2204e-16 : xn;

@@ -38,6 +38,31 @@ def test_single_rank_windows_bit_exact(n, seed):
             assert g.scalar(name) == o.scalar(name), name
 
 
+@pytest.mark.parametrize("nofold,kmax", [(True, None), (True, 4), (False, 4)])
+def test_both_reduction_routes_and_resumed_pcg_bit_exact(nofold, kmax, monkeypatch):
+    """Two routes to the totals of the workgroup partials: FOLDED (default while a rank has <= 1024 workgroups: every consumer adds them
+    up itself) and the REDUCTION LAUNCH big_k_fin (LPBOX_BIG_NOFOLD, or larger shards).  Same trees, so both must equal the oracle bit
+    for bit -- also when the PCG runs out of enqueued launches (LPBOX_BIG_KMAX=4 < the ~12 iterations it needs): the chain halts in
+    `post`, the launches behind it fall through, and the resumed PCG must still find the totals it halted on."""
+    from lpbox_hip.big import BigLp
+    from lpbox_hip.synth import make_auction_like
+    if nofold:
+        monkeypatch.setenv("LPBOX_BIG_NOFOLD", "1")
+    if kmax:
+        monkeypatch.setenv("LPBOX_BIG_KMAX", str(kmax))
+    P = make_auction_like(20000, 0)
+    g = BigLp(P)
+    g.solve_init()
+    assert g.scalar("folded_reductions") == (0.0 if nofold else 1.0)
+    o = oracle_for(P, g)
+    for (a, b) in ((0, 7), (7, 40)):
+        assert g.solve_iter(a, b) == o.solve_iter(a, b)
+        for name in ("x", "z1", "z2", "z4"):
+            assert bits_equal(g.vec(name), o.vec(name)), f"[{a},{b}) {name}"
+        assert (g.scalar("outer_total"), g.scalar("pcg_total")) == (o.total_outer_iters, o.total_pcg_iters)
+        assert g.scalar("cur_obj") == o.scalar("cur_obj")
+
+
 def test_column_sliced_rows_bit_exact(monkeypatch):
     """The slice-major row storage (the table gathered by E*v is cut into L2-sized column slices, lpbox_big_kernels.hip
     row_sum_sliced) keeps the ascending column order of every row sum: with slices of 1024 columns (20 slices here, long rows
@@ -110,13 +135,15 @@ def _rank(rank, world, port, q, iters):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,slice_kb", [(2, None), (3, None), (2, 8)])
-def test_variable_sharded_ranks_bit_exact_against_oracle_rank_model(world, slice_kb, monkeypatch):
+@pytest.mark.parametrize("world,slice_kb,nofold", [(2, None, False), (3, None, False), (2, 8, False), (2, None, True)])
+def test_variable_sharded_ranks_bit_exact_against_oracle_rank_model(world, slice_kb, nofold, monkeypatch):
     """W ranks (all on the test box's one GPU, contributions exchanged over gloo) against the oracle's model of the rank partition
     (per-rank sums added in rank order, oracle lpo_set_ranks): every iterate bit for bit -- not a comparison with a 1-rank HIP run."""
     import torch.multiprocessing as mp
     from lpbox_hip.synth import make_auction_like
     iters = 12
+    if nofold:                                                  # scalars through big_k_fin + all-gather + rank sum instead of gathered partials
+        monkeypatch.setenv("LPBOX_BIG_NOFOLD", "1")
     if slice_kb is not None:                                    # the column-sliced row storage inside every rank's shard (3 slices of 1 000 of the 3 000 local columns)
         monkeypatch.setenv("LPBOX_BIG_SLICE_KB", str(slice_kb))
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
