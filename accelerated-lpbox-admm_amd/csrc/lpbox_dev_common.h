@@ -162,12 +162,6 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double *red, int &par
         v[k] = t[k][0];
     }
 #endif
-#ifdef LPBOX_RED_NOSINK
-    // all totals exist HERE: without this the compiler sinks the partial loads + additions of a value that is only used behind a
-    // branch on another value (the PCG exit test) below that branch, i.e. a second LDS round trip on the critical path
-#pragma unroll
-    for (int k = 0; k < NV; k++) asm volatile("" : "+v"(v[k]));
-#endif
     parity ^= 1;
 }
 

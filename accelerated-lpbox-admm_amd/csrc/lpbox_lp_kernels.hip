@@ -357,34 +357,45 @@ __device__ __forceinline__ double uniform_f64(double v) {
 template <int MODE, int N, int STRIDE>
 struct SlotVec {
     double r[MODE == 1 ? 1 : N];
-    double *g;                                   // this thread's element of slot 0; slot s is STRIDE elements further
-    __device__ __forceinline__ void load(double *base) {
-        g = base;
+    // element of slot s = *(ub + boff + s * STRIDE * 8 bytes): ONE wave-uniform base (scalar registers) and ONE 32-bit BYTE offset per
+    // thread -- the `global_load v, v_off, s[base]` form.  (A per-thread 64-bit pointer per vector and slot -- what `base + tid`
+    // compiles to, the slot stride being beyond the 12-bit immediate offset of a global load -- cost the four-slot variant 32 registers,
+    // which it kept in scratch: every access of a cold vector was a scratch reload of its address followed by the dependent global
+    // access, 12 such pairs one after the other when the parked vectors came back after the PCG.)
+    char *ub;
+    unsigned boff;
+    __device__ __forceinline__ double *elem(int s) const {
+        unsigned o = boff;
+        asm volatile("" : "+v"(o));      // opaque: keeps the compiler from hoisting sixteen loop-invariant 64-bit addresses out of the ADMM loop (and spilling them)
+        return (double *)(ub + (o + (unsigned)(s * STRIDE * 8)));
+    }
+    __device__ __forceinline__ void load(double *uniform_base, unsigned thread_idx) {
+        ub = (char *)uniform_base; boff = thread_idx * 8u;
         if constexpr (MODE != 1) {
 #pragma unroll
-            for (int s = 0; s < N; s++) r[s] = base[s * STRIDE];
+            for (int s = 0; s < N; s++) r[s] = *elem(s);
         }
     }
-    __device__ __forceinline__ double get(int s) const { if constexpr (MODE == 1) return g[s * STRIDE]; else return r[s]; }
-    __device__ __forceinline__ void set(int s, double v) { if constexpr (MODE == 1) g[s * STRIDE] = v; else r[s] = v; }
+    __device__ __forceinline__ double get(int s) const { if constexpr (MODE == 1) return *elem(s); else return r[s]; }
+    __device__ __forceinline__ void set(int s, double v) { if constexpr (MODE == 1) *elem(s) = v; else r[s] = v; }
     __device__ __forceinline__ void park(bool dirty = true) {          // MODE 2: registers -> memory (nothing to write for a vector that never changes)
         if constexpr (MODE == 2) {
             if (dirty) {
 #pragma unroll
-                for (int s = 0; s < N; s++) g[s * STRIDE] = r[s];
+                for (int s = 0; s < N; s++) *elem(s) = r[s];
             }
         }
     }
     __device__ __forceinline__ void unpark() {                         // MODE 2: memory -> registers
         if constexpr (MODE == 2) {
 #pragma unroll
-            for (int s = 0; s < N; s++) r[s] = g[s * STRIDE];
+            for (int s = 0; s < N; s++) r[s] = *elem(s);
         }
     }
     __device__ __forceinline__ void store() const {
         if constexpr (MODE != 1) {
 #pragma unroll
-            for (int s = 0; s < N; s++) g[s * STRIDE] = r[s];
+            for (int s = 0; s < N; s++) *elem(s) = r[s];
         }
     }
 };
@@ -452,7 +463,7 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
     double x[EPT], dinv[EPT];
     SlotVec<LEAN ? 2 : 0, EPT, T> z1, z2, b;
     SlotVec<LEAN ? 1 : 0, EPT, T> pd;
-    z1.load(bd.z1 + on + tid); z2.load(bd.z2 + on + tid); b.load(bd.b + on + tid); pd.load(bd.pd + on + tid);
+    z1.load(bd.z1 + on, (unsigned)tid); z2.load(bd.z2 + on, (unsigned)tid); b.load(bd.b + on, (unsigned)tid); pd.load(bd.pd + on, (unsigned)tid);
     // Esq_diag_j = sum of squared entries of column j (LPcpp:2378-2390) = its length (entries are 1.0): needed only when the
     // diagonal is rebuilt (iteration 0, a fix, a rho update), so it is re-read from the layout instead of living in a register
     double Esq_reg[LEAN ? 1 : EPT];

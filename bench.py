@@ -579,6 +579,39 @@ def run_seg(args, ctx, cpu_leg=None):
 # ------------------------------------------------------------------------------------------------------------------------
 # config 5: one large LP, variable-sharded over the ranks
 # ------------------------------------------------------------------------------------------------------------------------
+XGMI_LINK_GBS = 153.0          # /opt/skills/guides/MI355X_MICROARCH.md: 7 xGMI links x ~153 GB/s per GPU, fully connected
+RCCL_OP_LATENCY_US = 15.0      # ASSUMED small-message latency of one RCCL operation on an 8-GPU node (10-20 us); no hardware to measure it
+
+
+def model_8_ranks(args, n, l, K, s_iter_1gpu, device):
+    """What the variable-sharded run should do on 8 ranks -- a MODEL put on record before hardware exists (no multi-GPU box was available):
+    local work of one rank + the exchanges of one outer iteration x an assumed latency + the bandwidth term of the l-vector exchanges.
+    Local work is MEASURED here on one GPU with an instance of n/8 variables (same generator; its row count is l/8, a real shard keeps
+    all l rows with 1/8 of their entries -- the l-sized kernels are under-counted, the launch-bound floor is not)."""
+    from lpbox_hip.big import BigLp
+    from lpbox_hip.synth import make_auction_like
+    P8 = make_auction_like(max(n // 8, 1000), 0)
+    g8 = BigLp(P8, device=device, use_torch_stream=True)
+    g8.solve_init(); g8.solve_iter(0, 100)                                  # warm (graphs, launch counts)
+    g8.solve_init()
+    import torch
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    g8.solve_iter(0, 100)
+    torch.cuda.synchronize(); local_s = (time.perf_counter() - t0) / 100
+    g8.close()
+    ops = 7 + 4 * K              # per outer iteration: prep 1, E*y1 2, resid 1, K x (E*p 2, p.Mp 1, (r.r, r.z) 1), post 1, E*x 2
+    vec_exchanges = K + 2        # E*v exchanges: row blocks sent to their owner (all 7 links at once), reduced blocks gathered back
+    bw_s = vec_exchanges * 2 * (l * 8 / 8) / (XGMI_LINK_GBS * 1e9)
+    lat_s = ops * RCCL_OP_LATENCY_US * 1e-6
+    t = local_s + lat_s + bw_s
+    return {"ms_per_iteration": 1e3 * t, "iterations_per_s": 1.0 / t, "speedup_vs_1_gpu_measured_here": s_iter_1gpu / t,
+            "local_work_ms": 1e3 * local_s, "rccl_operations_per_outer_iteration": ops, "latency_ms": 1e3 * lat_s, "bandwidth_ms": 1e3 * bw_s,
+            "assumed_us_per_rccl_operation": RCCL_OP_LATENCY_US, "xgmi_link_GBps": XGMI_LINK_GBS,
+            "note": "MODEL, not a measurement: the three exchanges of a PCG iteration are sequentially dependent in the reference's "
+                    "arithmetic, so their latency adds up; at the assumed latency 8 ranks buy little or nothing over one GPU "
+                    "(DESIGN.md section 10)"}
+
+
 def run_big(args, ctx, cpu_leg=None):
     rank, world, local_rank, sync, allred, backend = ctx.rank, ctx.world, ctx.local_rank, ctx.sync, ctx.allred, ctx.backend
     from lpbox_hip.big import BigLp
@@ -627,6 +660,10 @@ def run_big(args, ctx, cpu_leg=None):
                              "note": "chain-level: algorithmic bytes of an outer iteration (SURVEY 8d) / time per iteration, divided by "
                                      "the number of GPUs; per-kernel stats in profiles/"},
                 "detail": {"pcg_per_outer": K, "ms_per_iteration": 1e3 * s_iter, "backend": backend if world > 1 else None}}
+        line["detail"]["launches_per_iteration"] = launches_per_iter
+        line["detail"]["folded_reductions"] = bool(g.scalar("folded_reductions"))
+        if world == 1:
+            line["detail"]["model_8_ranks"] = model_8_ranks(args, n, l, K, s_iter, local_rank)
         if world == 1 and (args.cpu_sample is None or args.cpu_sample > 0):
             from oracle import oracle as O
             s = O.LpOracle(0)
