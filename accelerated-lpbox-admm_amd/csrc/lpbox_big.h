@@ -37,7 +37,7 @@ struct BigState {
     int pcg_total, outer_total, last_pcg, plain_iter_p1, pcg_max, expr_ready;
     int l2f, cc, n_live_lo, n_live_hi;      // l2f window semantics (LPcpp:1098-1574); x_iters column; live variables (all ranks), 2 x 31 bits
     double sum_fix_obj, fix_obj, prev_sum, prev_obj;
-    int pad0;
+    int rec;                                // plain loop: keep x of every iteration in xhist too (print_fix_info 2, LPcpp:903-909)
 };
 
 struct BigDev {

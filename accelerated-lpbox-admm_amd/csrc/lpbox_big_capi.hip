@@ -95,6 +95,7 @@ struct lpbox_big {
     long n_live_glob = 0;                 // live variables over all ranks
     int ws_cap = 0, xi_rows = 0;
     bool xi_valid = false;
+    bool record = false, xi_plain = false;   // lpbox_big_set_record: the plain loop stages every iterate; the last staged window came from it
     Buf<BigState> st;
     BigState hst;
 
@@ -297,6 +298,15 @@ int lpbox_big_set_stream(lpbox_big_t *h, void *hip_stream) {
     return LPBOX_OK;
 }
 
+// The plain loop's per-iteration dump (print_fix_info 2, LPcpp:777-780, :903-909) behind the size hand-over: the next lpbox_big_iterate
+// calls keep x after every iteration in the staging buffer the l2f window uses ([iterations][n_loc] on the device); read it back with
+// lpbox_big_get_x_iters(ws = iterations of the call).  Refused per call when the buffer would exceed 4 GiB.
+int lpbox_big_set_record(lpbox_big_t *h, int on) {
+    if (!h) return lpbox_fail(LPBOX_E_BADHANDLE, "bad handle");
+    h->record = on != 0;
+    return LPBOX_OK;
+}
+
 int lpbox_big_set_allgather(lpbox_big_t *h, lpbox_allgather_fn fn, void *user) {
     if (!h) return lpbox_fail(LPBOX_E_BADHANDLE, "bad handle");
     // the exchange buffers are sized by lpbox_big_init from the transport that is set then (as for lpbox_big_rccl_init)
@@ -494,9 +504,26 @@ int lpbox_big_iterate(lpbox_big_t *h, int iter_start, int iter_end, int *ret) { 
     if (!h) return lpbox_fail(LPBOX_E_BADHANDLE, "bad handle");
     if (!h->inited) return lpbox_fail(LPBOX_E_STATE, "solve_init has not been called");
     CHK(use_device(h));
+    const int ws = iter_end - iter_start;
+    const bool rec = h->record && ws > 0;
+    if (rec) {
+        if ((double)ws * h->n_loc * sizeof(double) > 4294967296.0)
+            return lpbox_fail(LPBOX_E_UNSUPPORTED, "recording %d iterations of %d variables needs more than 4 GiB", ws, h->n_loc);
+        if (h->ws_cap < ws || !h->xhist.p) {
+            HIPCHK(hipStreamSynchronize(h->stream));
+            HIPCHK(h->xhist.alloc((size_t)ws * h->n_loc));
+            for (auto &kv : h->gexec) (void)hipGraphExecDestroy(kv.second);         // the captured launches carry the old buffer
+            h->gexec.clear();
+            h->ws_cap = ws;
+        }
+        HIPCHK(hipMemsetAsync(h->xhist.p, 0, sizeof(double) * (size_t)h->ws_cap * h->n_loc, h->stream));
+        h->xi_left = h->left_idx; h->xi_rows = (int)h->left_idx.size();
+        if (h->xi_rows) HIPCHK(hipMemcpyAsync(h->d_live_idx.p, h->xi_left.data(), sizeof(int) * (size_t)h->xi_rows, hipMemcpyHostToDevice, h->stream));
+    }
     const BigDev d = h->dev();
-    HIPCHK(big_launch_set_window(d, iter_start, iter_end, 0, &h->parity, h->stream));
+    HIPCHK(big_launch_set_window(d, iter_start, iter_end, rec ? 2 : 0, &h->parity, h->stream));
     CHK(run_window(h, d, iter_end));
+    if (rec) { h->xi_valid = true; h->xi_plain = true; }
     if (ret) *ret = h->hst.ret;
     return LPBOX_OK;
 }
@@ -560,7 +587,7 @@ int lpbox_big_iterate_l2f(lpbox_big_t *h, int iter_start, int iter_end, const do
     if (h->ws_cap > 0) HIPCHK(hipMemsetAsync(h->xhist.p, 0, sizeof(double) * (size_t)h->ws_cap * h->n_loc, h->stream));   // x_iters = Zero (:1113): ALL staged columns, also those of an earlier, longer window
     if (h->xi_rows) HIPCHK(hipMemcpyAsync(h->d_live_idx.p, h->xi_left.data(), sizeof(int) * (size_t)h->xi_rows, hipMemcpyHostToDevice, h->stream));
     CHK(run_window(h, d, iter_end));        // synchronises: nf / xi_left stay alive until here
-    h->xi_valid = true;
+    h->xi_valid = true; h->xi_plain = false;
     if (ret) *ret = h->hst.ret;
     return LPBOX_OK;
 }
@@ -574,7 +601,8 @@ int lpbox_big_get_n(lpbox_big_t *h) {                                           
 int lpbox_big_get_x_iters_device(lpbox_big_t *h, int ws, void **dev_ptr, int *rows) {
     if (!h || !h->inited) return lpbox_fail(LPBOX_E_STATE, "not initialised");
     if (!h->xi_valid) return lpbox_fail(LPBOX_E_STATE, "solve_iter_l2f has not been called");
-    if (ws <= 0 || ws > LP_XITERS_COLS) return lpbox_fail(LPBOX_E_BADARG, "ws = %d outside (0,%d]", ws, LP_XITERS_COLS);
+    const int ws_max = h->xi_plain ? h->ws_cap : LP_XITERS_COLS;                 // a recorded plain call may be longer than an l2f window
+    if (ws <= 0 || ws > ws_max) return lpbox_fail(LPBOX_E_BADARG, "ws = %d outside (0,%d]", ws, ws_max);
     CHK(use_device(h));
     const size_t need = (size_t)std::max(h->xi_rows, 1) * ws;
     if (h->xi_out.count < need) { HIPCHK(hipStreamSynchronize(h->stream)); HIPCHK(h->xi_out.alloc(need)); }

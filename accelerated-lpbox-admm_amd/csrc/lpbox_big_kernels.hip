@@ -130,7 +130,7 @@ __global__ void big_k_set_window(BigDev d, int in, int out, int iter_start, int 
     d.st[out] = d.st[in];
     BigState *s = d.st + out;
     s->iter = iter_start; s->iter_start = iter_start; s->iter_end = iter_end; s->ret = 0; s->stop = LP_STOP_NONE; s->halt = BIG_HALT_NONE;
-    s->l2f = l2f; s->cc = 0;
+    s->l2f = l2f & 1; s->rec = (l2f >> 1) & 1; s->cc = 0;
 }
 
 __global__ void big_k_resume(BigDev d, int in, int out, int reset_pcg_max) {
@@ -568,7 +568,7 @@ __global__ void __launch_bounds__(T) big_k_post(BigDev d, int in, int out) {
         return;
     }
     const double g1 = si->gamma_val * si->rho1, g2 = si->gamma_val * si->rho2;
-    double *xh = (si->l2f && d.xhist && si->cc < d.ws_cap) ? d.xhist + (size_t)si->cc * d.n_loc : nullptr;
+    double *xh = ((si->l2f || si->rec) && d.xhist && si->cc < d.ws_cap) ? d.xhist + (size_t)si->cc * d.n_loc : nullptr;
     double e5[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     for (int q = 0; q < d.EPT; q++) {
         const int j = blockIdx.x * (T * d.EPT) + q * T + threadIdx.x;
@@ -591,7 +591,7 @@ __global__ void __launch_bounds__(T) big_k_post(BigDev d, int in, int out) {
         d.st[out] = *si;
         BigState *s = d.st + out;
         s->pcg_done = 1; s->last_pcg = k; s->pcg_total += k; s->outer_total++;
-        if (si->l2f) s->cc = si->cc + 1;
+        if (si->l2f || si->rec) s->cc = si->cc + 1;
         if (k > s->pcg_max) s->pcg_max = k;
         s->phase = 3;
     }

@@ -84,6 +84,7 @@ SYMBOLS = {
     "lpbox_big_set_problem": (C.c_int, [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, _ip, _ip, _dp, C.c_void_p]),
     "lpbox_big_init": (C.c_int, [C.c_void_p]),
     "lpbox_big_iterate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "lpbox_big_set_record": (C.c_int, [C.c_void_p, C.c_int]),
     "lpbox_big_iterate_l2f": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_long, C.POINTER(C.c_int)]),
     "lpbox_big_get_n": (C.c_int, [C.c_void_p]),
     "lpbox_big_get_x_iters": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),

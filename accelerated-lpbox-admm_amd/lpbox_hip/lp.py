@@ -265,7 +265,7 @@ class _LargeInstance:
     quirks, its own (two-level) summation order -- bit-exact against the oracle in that order (tests/test_dropin_large_gpu.py)."""
 
     B = 1
-    can_record = False       # the plain loop's per-iteration dump (print_info 2/3) is not staged on this path
+    can_record = True        # the plain loop's per-iteration dump (print_info 2/3): lpbox_big_set_record stages the iterates on the device
 
     def __init__(self, problem, device=None):
         from .big import BigLp
@@ -280,7 +280,7 @@ class _LargeInstance:
         return self._g.solve_init()
 
     def set_record(self, on=True):
-        return None
+        check(self._g._L.lpbox_big_set_record(self._g._h, 1 if on else 0), "lpbox_big_set_record")
 
     def solve_iter(self, i, j):
         return np.array([self._g.solve_iter(_as_int(i, "i"), _as_int(j, "j"))], np.int32)
@@ -419,7 +419,10 @@ class PyLPboxADMMsolver:
     def solve_iter(self, i, j):
         out_dir = self._xiter_dir()
         dump = out_dir is not None and self.print_info in (2, 3) and _as_int(j, "j") > _as_int(i, "i") and getattr(self._b, "can_record", True)
-        self._b.set_record(dump)
+        # print_info 3 writes only the iterate of the stop (LPcpp:940-946): on the large-instance route that is read back after the solve
+        # instead of staging every iterate of a long call in HBM
+        self._final_only = dump and self.print_info == 3 and isinstance(self._b, _LargeInstance)
+        self._b.set_record(dump and not self._final_only)
         t0 = time.perf_counter()
         ret = int(self._b.solve_iter(i, j)[0])
         secs = int((time.perf_counter() - t0) * 1000) / 1000.0          # the reference truncates to whole ms (LPcpp:1079-1080)
@@ -439,7 +442,10 @@ class PyLPboxADMMsolver:
     def _write_plain_files(self, out_dir, i, j, secs, dump):
         fi, k, jj = self._file_id
         reason, p1 = self._b.stop(0)
-        if dump:
+        if dump and getattr(self, "_final_only", False):
+            if reason in (1, 2):
+                files.write_xiters_csv(os.path.join(out_dir, "%d_%d_xiters_%d.csv" % (k, jj, fi)), self._b.get_final_x_sol(0).reshape(1, -1), p1 - 1)
+        elif dump:
             done = (p1 - i) if reason in (1, 2) else (j - i)           # iterations this call ran (break leaves iter at the stop)
             X = self._b.get_x_iters_2d(j - i, 0)[:, :done].T           # one row per iteration
             lo = 0 if self.print_info == 2 else (done - 1 if reason in (1, 2) else done)   # 3: only the iterate of the stop

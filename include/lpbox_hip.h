@@ -226,6 +226,9 @@ int lpbox_big_set_problem(lpbox_big_t *h, long n_glob, int c0, int n_loc, int l,
                           const double *b, const double *f);
 int lpbox_big_init(lpbox_big_t *h);                                             /* ADMM_lp_iters_init LPcpp:489-763 */
 int lpbox_big_iterate(lpbox_big_t *h, int iter_start, int iter_end, int *ret);  /* ADMM_lp_iters      LPcpp:766-1095 */
+/* print_fix_info 2 behind the size hand-over (LPcpp:777-780, :903-909): the following lpbox_big_iterate calls keep x after every
+ * iteration on the device; lpbox_big_get_x_iters(ws = iterations of the call) reads the (rows x ws) block back. */
+int lpbox_big_set_record(lpbox_big_t *h, int on);
 /* ADMM_lp_iters_l2f (LPcpp:1098-1574) on the sharded instance.  vec_local: this rank's slice of the fix vector, one entry per LOCAL
  * live variable in ascending order (1.0 / 0.0 fix, anything else leave); num_global: number of fixes over ALL ranks (callers sum their
  * local counts with one tiny all-reduce; it sets the shrunken n of the sphere projection, LPcpp:427).  x_iters of the window stay on

@@ -79,3 +79,41 @@ def test_oversize_plain_solve_and_file_route(tmp_path):
     g.set_problem(S["n"], S["l"], S["colptr"], S["rowidx"], S["b"])
     g.solve_init()
     assert not g.large and g.get_n() == 300
+
+
+@pytest.mark.parametrize("print_info", [2, 3])
+def test_oversize_instance_writes_the_iterate_dump(print_info, tmp_path):
+    """print_info 2 (every iterate, LPcpp:777-780, :903-909) and 3 (the iterate of the stop, :940-946) behind the size hand-over: the file
+    route of the drop-in class writes <root>/xiter/<k>_<j>_xiters_<i>.csv for an instance the on-chip kernel does not hold, and every
+    printed row is the oracle's iterate to the printed digits."""
+    from lpbox_hip import files
+    from lpbox_hip.lp import PyLPboxADMMsolver
+    from lpbox_hip.synth import make_auction_like, write_instance_files
+    P = make_auction_like(2300, 7)
+    d = tmp_path / "instance" / "1000_2300"
+    os.makedirs(d)
+    write_instance_files(P, str(d / "instance_1_C.txt"), str(d / "instance_1_b.txt"))
+    g = PyLPboxADMMsolver(print_info)
+    g.data_root = str(tmp_path)
+    g.write_files = True
+    g.read_File(1, 1000, 2300)
+    g.solve_init()
+    assert g.large
+    o = _oracle(P, g)
+    iters = 40 if print_info == 2 else 20000
+    assert g.solve_iter(0, iters) == o.solve_iter(0, iters)
+    path = tmp_path / "xiter" / "1000_2300_xiters_1.csv"
+    if print_info == 2:
+        X = files.read_xiters_csv(str(path))                              # (n, iterations), as LP/trainer.py:32-48 reads it
+        assert X.shape == (P["n"], 40)
+        for k in (0, 1, 39):                  # (a fresh oracle per column: a resumed plain call overwrites z4 on its first iteration, LPcpp:920-923)
+            o2 = _oracle(P, g)
+            o2.solve_iter(0, k + 1)
+            assert np.array_equal(X[:, k], np.array([float("%f" % v) for v in o2.vec("x")])), k
+    else:
+        reason, p1 = g.batch.stop(0)
+        assert reason in (1, 2)
+        lines = open(path).read().splitlines()
+        assert len(lines) == 1 and lines[0] == "Iter%d," % p1 + ",".join("%f" % v for v in o.vec("x"))
+    rec = files.read_results_csv(str(tmp_path / "xiter" / "allres.csv"))
+    assert len(rec) == 1 and rec[0][0] == 1 and rec[0][2] == g.batch.stop(0)[1]
