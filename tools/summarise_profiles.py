@@ -51,4 +51,10 @@ for name in ("prof_bench", "prof_policy", "prof_big", "prof_seg"):
         if ln.startswith("{") or ln.startswith("rows ") or ln.startswith("n="):
             print(name, ln.strip()[:300])
         if ln.startswith("{") and name in ("prof_bench", "prof_c4", "prof_big", "prof_seg"):     # the bench line of the profiled run itself
-            open(os.path.join(P, rnd + "_" + name[5:] + "_bench_line.json"), "w").write(ln)
+            d = json.loads(ln)
+            d["profiler_mode"] = True
+            d["profiler_note"] = ("printed by the run rocprofv3 was tracing" + (" with hipGraph replay OFF (LPBOX_*_NOGRAPH=1: eager launches, so that "
+                                  "every kernel appears in the trace)" if name in ("prof_big", "prof_seg") else "") +
+                                  ": it documents what the kernel statistics next to it belong to, it is NOT the benchmark figure of this "
+                                  "configuration (that is " + rnd + "_bench_config*.json / the driver's BENCH record)")
+            open(os.path.join(P, rnd + "_" + name[5:] + "_profiled_run_line.json"), "w").write(json.dumps(d) + "\n")
