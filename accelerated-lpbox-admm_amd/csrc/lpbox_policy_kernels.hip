@@ -24,6 +24,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "lpbox_policy.h"
 
@@ -47,7 +48,6 @@ using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int PT = POLICY_THREADS;     // 512
 constexpr int PM = POLICY_TOKENS_PER_WG;   // 160
 constexpr int E = 128;
 constexpr int LDA = 136;               // halves per row of a 128-wide LDS image
@@ -81,16 +81,44 @@ __device__ __forceinline__ void load_w(WFrag<NT> &w, const f16x8 *wp, int tile0,
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) w.v[ks][nt] = wp[((size_t)(tile0 + nt * tstride) * 4 + ks) * 64 + lane];
 }
+// the wave's tiles of one Q|K|V block of four heads (12 feature tiles: Q of heads 0-3, K, V): PER of each third, starting at head PER * wn
+template <int PER>
+__device__ __forceinline__ void load_w_qkv(WFrag<3 * PER> &w, const f16x8 *wp, int wn, int lane) {
+#pragma unroll
+    for (int nt = 0; nt < 3 * PER; nt++)
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) w.v[ks][nt] = wp[((size_t)((nt / PER) * 4 + wn * PER + nt % PER) * 4 + ks) * 64 + lane];
+}
 
 // acc[mt][nt] += (W^T)[this wave's NT feature tiles][0,128) * (ACT^T)[0,128)[this wave's 5 token tiles]
 // The weights are the MFMA's A operand and the activations its B operand, so a lane ends up with 4 CONSECUTIVE FEATURES of one
 // token: element r of acc[mt][nt] is token row0 + 16 mt + (lane & 15), feature 16 (tile0 + nt) + 4 (lane >> 4) + r, and an
 // epilogue stores it as one 8-byte LDS write.  ACT: LDS fp16 image with row stride lda (halves).
-// LAST_PLAIN: the last feature tile is computed the other way round (activations = A operand): its lanes then hold 4 consecutive
+// PLAIN: the last PLAIN feature tiles are computed the other way round (activations = A operand): its lanes then hold 4 consecutive
 // TOKENS of one feature, which is what the transposed V image wants.
-template <int NT, bool LAST_PLAIN = false>
+template <int NT, int PLAIN = 0>
 __device__ __forceinline__ void gemm_tiles(const f16 *act, int lda, int row0, const WFrag<NT> &w, f32x4 (&acc)[MT][NT], int lane) {
     const f16 *arow = act + (size_t)(row0 + (lane & 15)) * lda + 8 * (lane >> 4);
+    if constexpr (NT >= 4) {
+        // one wave per SIMD (the 2 x 2 wave grid): nobody else hides the LDS latency, so the activation fragments of k-step ks + 1 are
+        // requested before the MFMAs of k-step ks are issued (two register sets of MT fragments)
+        f16x8 a[2][MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) a[0][mt] = *(const f16x8 *)(arow + (size_t)mt * 16 * lda);
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+            if (ks < 3) {
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) a[(ks + 1) & 1][mt] = *(const f16x8 *)(arow + (size_t)mt * 16 * lda + (ks + 1) * 32);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++)
+                    acc[mt][nt] = (nt >= NT - PLAIN) ? mfma16(a[ks & 1][mt], w.v[ks][nt], acc[mt][nt]) : mfma16(w.v[ks][nt], a[ks & 1][mt], acc[mt][nt]);
+        }
+        return;
+    }
 #pragma unroll
     for (int ks = 0; ks < 4; ks++) {
 #pragma unroll
@@ -98,7 +126,7 @@ __device__ __forceinline__ void gemm_tiles(const f16 *act, int lda, int row0, co
             const f16x8 a = *(const f16x8 *)(arow + (size_t)mt * 16 * lda + ks * 32);
 #pragma unroll
             for (int nt = 0; nt < NT; nt++)
-                acc[mt][nt] = (LAST_PLAIN && nt == NT - 1) ? mfma16(a, w.v[ks][nt], acc[mt][nt]) : mfma16(w.v[ks][nt], a, acc[mt][nt]);
+                acc[mt][nt] = (nt >= NT - PLAIN) ? mfma16(a, w.v[ks][nt], acc[mt][nt]) : mfma16(w.v[ks][nt], a, acc[mt][nt]);
         }
     }
 }
@@ -123,12 +151,19 @@ __device__ __forceinline__ void store4(f16 *dst, float a, float b, float c, floa
     *(f16x4 *)dst = h;
 }
 
-template <int TOK>
-__global__ void __launch_bounds__(PT) policy_body_kernel(PolicyArgs pa) {
+// NW = column groups of the wave grid (2 x NW waves).  NW = 4: eight waves, 80 x 32 outputs each (two waves per SIMD).  NW = 2: four waves
+// of 80 x 64 (one per SIMD, up to 512 registers each): every activation fragment read from LDS feeds twice as many MFMAs, i.e. half
+// the LDS fragment traffic per GEMM -- the resource that was level with the MFMA time in the eight-wave form.
+template <int TOK, int NW>
+__global__ void __launch_bounds__(128 * NW) policy_body_kernel(PolicyArgs pa) {
+    constexpr int PT = 128 * NW;                    // threads
+    constexpr int NTO = 8 / NW;                     // feature tiles per wave of a 128-wide GEMM output
+    constexpr int PER = 4 / NW;                     // heads per wave of a Q|K|V block of four heads
+    constexpr int NTQ = 3 * PER;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Lds &S = *reinterpret_cast<Lds *>(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / NW, wn = wave % NW;
     const int row0 = wm * 80;                       // first token of this wave's 5 token tiles
     const int l15 = lane & 15, g4 = (lane >> 4) * 4;
     constexpr int VARS = PM / TOK;                  // variables per workgroup
@@ -136,9 +171,9 @@ __global__ void __launch_bounds__(PT) policy_body_kernel(PolicyArgs pa) {
     const int nvar = (int)min((long)VARS, pa.rows - var0);
     const f16x8 *wbase = reinterpret_cast<const f16x8 *>(pa.weights);
 
-    WFrag<3> w3a, w3b;
-    WFrag<2> w2a, w2b;
-    load_w<3>(w3a, wbase, wn, 4, lane);             // layer 0: feature tile wn of each of Q, K, V (heads 0-3)
+    WFrag<NTQ> w3a, w3b;
+    WFrag<NTO> w2a, w2b;
+    load_w_qkv<PER>(w3a, wbase, wn, lane);          // layer 0: this wave's feature tiles of Q, K, V (heads 0-3)
 
     // ---- stage x (fp64 in the solver's buffer) as float [160][5] in the `ao` region; zero the pad rows of Q/K/V ----
     float *xs = reinterpret_cast<float *>(S.ao);
@@ -157,12 +192,12 @@ __global__ void __launch_bounds__(PT) policy_body_kernel(PolicyArgs pa) {
     __syncthreads();
 
     // ---- embedding: H = x W_in + (position code W_pos + bias), straight into the accumulator layout ----
-    f32x4 H[MT][2];
+    f32x4 H[MT][NTO];
     {
         const float *win = pa.consts + POLICY_OFF_WIN, *bin = pa.consts + POLICY_OFF_BIN;
 #pragma unroll
-        for (int nt = 0; nt < 2; nt++) {
-            const int f0 = (wn * 2 + nt) * 16 + g4;
+        for (int nt = 0; nt < NTO; nt++) {
+            const int f0 = (wn * NTO + nt) * 16 + g4;
             f32x4 w[5];
 #pragma unroll
             for (int c = 0; c < 5; c++) w[c] = *(const f32x4 *)(win + c * E + f0);
@@ -180,8 +215,8 @@ __global__ void __launch_bounds__(PT) policy_body_kernel(PolicyArgs pa) {
 #pragma unroll
     for (int mt = 0; mt < MT; mt++)
 #pragma unroll
-        for (int nt = 0; nt < 2; nt++)
-            store4(S.h + (row0 + mt * 16 + l15) * LDA + (wn * 2 + nt) * 16 + g4, H[mt][nt][0], H[mt][nt][1], H[mt][nt][2], H[mt][nt][3]);
+        for (int nt = 0; nt < NTO; nt++)
+            store4(S.h + (row0 + mt * 16 + l15) * LDA + (wn * NTO + nt) * 16 + g4, H[mt][nt][0], H[mt][nt][1], H[mt][nt][2], H[mt][nt][3]);
     __syncthreads();
 
 #pragma unroll
@@ -193,17 +228,22 @@ __global__ void __launch_bounds__(PT) policy_body_kernel(PolicyArgs pa) {
 #pragma unroll
         for (int half = 0; half < 2; half++) {
             {   // Q | K | V of heads 4 half .. 4 half + 3:  (160 x 128) x (128 x 192); meanwhile fetch the next GEMM's weights
-                f32x4 acc[MT][3];
-                zero_acc<3>(acc);
-                if (half == 0) { load_w<3>(w3b, wl + (size_t)48 * 64, wn, 4, lane); gemm_tiles<3, true>(S.h, LDA, row0, w3a, acc, lane); }
-                else           { load_w<2>(w2a, wl + (size_t)96 * 64, wn * 2, 1, lane); gemm_tiles<3, true>(S.h, LDA, row0, w3b, acc, lane); }
+                f32x4 acc[MT][NTQ];
+                zero_acc<NTQ>(acc);
+                if (half == 0) { load_w_qkv<PER>(w3b, wl + (size_t)48 * 64, wn, lane); gemm_tiles<NTQ, PER>(S.h, LDA, row0, w3a, acc, lane); }
+                else           { load_w<NTO>(w2a, wl + (size_t)96 * 64, wn * NTO, 1, lane); gemm_tiles<NTQ, PER>(S.h, LDA, row0, w3b, acc, lane); }
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++) {
                     const int tok = row0 + mt * 16 + l15;
-                    store4(S.u.a.q + tok * LDQ + wn * 16 + g4, acc[mt][0][0], acc[mt][0][1], acc[mt][0][2], acc[mt][0][3]);
-                    store4(S.u.a.k + tok * LDQ + wn * 16 + g4, acc[mt][1][0], acc[mt][1][1], acc[mt][1][2], acc[mt][1][3]);
-                    // V tile: lane = feature wn*16 + l15, registers = tokens row0 + 16 mt + g4 .. + 3
-                    store4(S.u.a.vt + (wn * 16 + l15) * LDV + row0 + mt * 16 + g4, acc[mt][2][0], acc[mt][2][1], acc[mt][2][2], acc[mt][2][3]);
+#pragma unroll
+                    for (int j = 0; j < PER; j++) {
+                        const int hd = wn * PER + j;           // head (of the four of this half) = feature tile inside Q, K, V
+                        store4(S.u.a.q + tok * LDQ + hd * 16 + g4, acc[mt][j][0], acc[mt][j][1], acc[mt][j][2], acc[mt][j][3]);
+                        store4(S.u.a.k + tok * LDQ + hd * 16 + g4, acc[mt][PER + j][0], acc[mt][PER + j][1], acc[mt][PER + j][2], acc[mt][PER + j][3]);
+                        // V tile: lane = feature hd*16 + l15, registers = tokens row0 + 16 mt + g4 .. + 3
+                        store4(S.u.a.vt + (hd * 16 + l15) * LDV + row0 + mt * 16 + g4, acc[mt][2 * PER + j][0], acc[mt][2 * PER + j][1],
+                               acc[mt][2 * PER + j][2], acc[mt][2 * PER + j][3]);
+                    }
                 }
             }
             __syncthreads();
@@ -285,13 +325,13 @@ __global__ void __launch_bounds__(PT) policy_body_kernel(PolicyArgs pa) {
 
         // ================= output projection + residual + BatchNorm (eval) =================
         {
-            f32x4 acc[MT][2];
-            zero_acc<2>(acc);
-            load_w<2>(w2b, wl + (size_t)128 * 64, wn * 2, 1, lane);              // FF-up chunk 0
-            gemm_tiles<2>(S.ao, LDA, row0, w2a, acc, lane);
+            f32x4 acc[MT][NTO];
+            zero_acc<NTO>(acc);
+            load_w<NTO>(w2b, wl + (size_t)128 * 64, wn * NTO, 1, lane);          // FF-up chunk 0
+            gemm_tiles<NTO>(S.ao, LDA, row0, w2a, acc, lane);
 #pragma unroll
-            for (int nt = 0; nt < 2; nt++) {
-                const int f0 = (wn * 2 + nt) * 16 + g4;
+            for (int nt = 0; nt < NTO; nt++) {
+                const int f0 = (wn * NTO + nt) * 16 + g4;
                 const f32x4 s1 = *(const f32x4 *)(cl + POLICY_LC_S1 + f0), t1 = *(const f32x4 *)(cl + POLICY_LC_T1 + f0);
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++) {
@@ -305,18 +345,18 @@ __global__ void __launch_bounds__(PT) policy_body_kernel(PolicyArgs pa) {
 
         // ================= feed-forward 128 -> 512 -> 128, hidden layer in four 128-wide chunks =================
         {
-            f32x4 acc2[MT][2];
-            zero_acc<2>(acc2);
+            f32x4 acc2[MT][NTO];
+            zero_acc<NTO>(acc2);
 #pragma unroll
             for (int c = 0; c < POL_FF_CHUNKS; c++) {
                 {
-                    f32x4 acc[MT][2];
-                    zero_acc<2>(acc);
-                    load_w<2>(w2a, wl + (size_t)(256 + c * 32) * 64, wn * 2, 1, lane);      // FF-down chunk c
-                    gemm_tiles<2>(S.h, LDA, row0, w2b, acc, lane);
+                    f32x4 acc[MT][NTO];
+                    zero_acc<NTO>(acc);
+                    load_w<NTO>(w2a, wl + (size_t)(256 + c * 32) * 64, wn * NTO, 1, lane);  // FF-down chunk c
+                    gemm_tiles<NTO>(S.h, LDA, row0, w2b, acc, lane);
 #pragma unroll
-                    for (int nt = 0; nt < 2; nt++) {
-                        const int f0 = (wn * 2 + nt) * 16 + g4;
+                    for (int nt = 0; nt < NTO; nt++) {
+                        const int f0 = (wn * NTO + nt) * 16 + g4;
                         const f32x4 b1 = *(const f32x4 *)(cl + POLICY_LC_B1 + c * E + f0);
 #pragma unroll
                         for (int mt = 0; mt < MT; mt++) {
@@ -326,14 +366,14 @@ __global__ void __launch_bounds__(PT) policy_body_kernel(PolicyArgs pa) {
                     }
                 }
                 __syncthreads();
-                if (c < 3) load_w<2>(w2b, wl + (size_t)(128 + (c + 1) * 32) * 64, wn * 2, 1, lane);                 // next FF-up chunk
-                else if (layer == 0) load_w<3>(w3a, wbase + (size_t)POLICY_FRAGS_PER_LAYER * 64, wn, 4, lane);  // next layer's Q|K|V
-                gemm_tiles<2>(S.u.ff, LDA, row0, w2a, acc2, lane);
+                if (c < 3) load_w<NTO>(w2b, wl + (size_t)(128 + (c + 1) * 32) * 64, wn * NTO, 1, lane);             // next FF-up chunk
+                else if (layer == 0) load_w_qkv<PER>(w3a, wbase + (size_t)POLICY_FRAGS_PER_LAYER * 64, wn, lane);  // next layer's Q|K|V
+                gemm_tiles<NTO>(S.u.ff, LDA, row0, w2a, acc2, lane);
                 __syncthreads();
             }
 #pragma unroll
-            for (int nt = 0; nt < 2; nt++) {
-                const int f0 = (wn * 2 + nt) * 16 + g4;
+            for (int nt = 0; nt < NTO; nt++) {
+                const int f0 = (wn * NTO + nt) * 16 + g4;
                 const f32x4 b2 = *(const f32x4 *)(cl + POLICY_LC_B2 + f0), s2 = *(const f32x4 *)(cl + POLICY_LC_S2 + f0),
                             t2 = *(const f32x4 *)(cl + POLICY_LC_T2 + f0);
 #pragma unroll
@@ -365,20 +405,20 @@ size_t policy_lds_bytes() { return sizeof(Lds); }
 hipError_t policy_launch_body(const PolicyArgs &pa, int tokens, hipStream_t s) {
     if (pa.rows <= 0) return hipSuccess;
     const size_t lds = sizeof(Lds);
-    if (tokens == 20) {
-        const long groups = (pa.rows + (PM / 20) - 1) / (PM / 20);
-        hipError_t e = hipFuncSetAttribute((const void *)policy_body_kernel<20>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // eight waves of 80 x 32 outputs (default) or LPBOX_POLICY_WAVES=4: four waves of 80 x 64.  Measured (128 000 variables, forward incl.
+    // the head): 3.68 vs 4.38 ms -- the wider tile does take 19 % off the FF GEMMs (1.20 -> 0.97 ms: half the LDS fragment traffic), but
+    // with one wave per SIMD the attention phase (0.72 -> 1.10 ms) and the QKV / projection / IO phases (1.76 -> 2.31 ms) lose more.
+    const bool eight = !(getenv("LPBOX_POLICY_WAVES") && atoi(getenv("LPBOX_POLICY_WAVES")) == 4);
+    if (tokens != 20 && tokens != 5) return hipErrorInvalidValue;
+    const long groups = (pa.rows + (PM / tokens) - 1) / (PM / tokens);
+    auto go = [&](auto kernel, int threads) {
+        hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(policy_body_kernel<20>, dim3((unsigned)groups), dim3(PT), lds, s, pa);
-    } else if (tokens == 5) {
-        const long groups = (pa.rows + (PM / 5) - 1) / (PM / 5);
-        hipError_t e = hipFuncSetAttribute((const void *)policy_body_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(policy_body_kernel<5>, dim3((unsigned)groups), dim3(PT), lds, s, pa);
-    } else {
-        return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
+        hipLaunchKernelGGL(kernel, dim3((unsigned)groups), dim3(threads), lds, s, pa);
+        return hipGetLastError();
+    };
+    if (tokens == 20) return eight ? go(policy_body_kernel<20, 4>, 512) : go(policy_body_kernel<20, 2>, 256);
+    return eight ? go(policy_body_kernel<5, 4>, 512) : go(policy_body_kernel<5, 2>, 256);
 }
 
 // =====================================================================================================================

@@ -165,3 +165,17 @@ def test_training_step_reduces_the_loss_cpu():
         labels.append(y)
     losses = train(net, hist, labels, epochs=6, lr=1e-3)
     assert losses[-1] < 0.7 * losses[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tokens", [20, 5])
+def test_four_wave_geometry_of_the_fused_encoder_gives_the_same_bits(tokens, monkeypatch):
+    """LPBOX_POLICY_WAVES=4 (2 x 2 waves of 80 x 64 outputs; measured slower than the default 2 x 4 of 80 x 32, kept as a tuning knob):
+    every output element accumulates the same products in the same k order, so the encoder output must be identical."""
+    sd = P.random_state(tokens, seed=3)
+    fused = P.FusedEarlyFixPolicy(sd, tokens=tokens, device="cuda", decision_band=0.0)
+    x = torch.rand(3001, tokens, 5, generator=torch.Generator().manual_seed(1)).cuda()
+    a = fused.logits(x).cpu().numpy()
+    monkeypatch.setenv("LPBOX_POLICY_WAVES", "4")
+    b = fused.logits(x).cpu().numpy()
+    assert np.array_equal(a, b)
