@@ -772,7 +772,7 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
                 double q[EPT];
                 rows_gather_at(std::integral_constant<int, GX2>{}, q);    // q = E y1 (the start vector sits in the second n-vector)
 #pragma unroll
-                for (int s = 0; s < EPT; s++) if (rvalid(s)) gl[3 * rgl(s) + 2] = q[s];
+                for (int s = 0; s < EPT; s++) if (rvalid(s)) gl[3 * rgl(s) + 2] = r4 * q[s];   // the factor of the column product, once per row (see the PCG loop)
                 __syncthreads();
             }
             if (rhoUpdated) {                                         // DiagonalPreconditioner::compute (:883-890)
@@ -881,7 +881,7 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
             double r[EPT], p[EPT];
             double p3[3] = {0.0, 0.0, 0.0};
             double tcol[EPT];
-            cols_gather(std::integral_constant<int, 2>{}, op_scaled, tcol);
+            cols_gather(std::integral_constant<int, 2>{}, op_add, tcol);
 #pragma unroll
             for (int s = 0; s < EPT; s++) {
                 const double t = tcol[s];
@@ -921,7 +921,14 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
 #endif
                             STAMP(4)
 #pragma unroll
+                            // the column product adds (rho4 * 1.0) * q_i per ENTRY (LPcpp:115-162): that product is the same value for every
+                            // column that meets row i, so the row's owner forms it once and publishes r4 * q_i -- one multiplication per row
+                            // instead of one per entry of E in the gather below; fl(acc + fl(r4 * q_i)) is unchanged bit for bit
+#ifdef LPBOX_KO_NOMUL
                             for (int s = 0; s < EPT; s++) if (rvalid(s)) gl[3 * rgl(s)] = q[s];
+#else
+                            for (int s = 0; s < EPT; s++) if (rvalid(s)) gl[3 * rgl(s)] = r4 * q[s];
+#endif
                         }
                         STAMP_PRE(13)
                         __syncthreads();
@@ -931,7 +938,7 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
 #ifdef LPBOX_KO_COLS
                         for (int s = 0; s < EPT; s++) tcol[s] = gl[3 * (tid % 128)];
 #else
-                        cols_gather(std::integral_constant<int, 0>{}, op_scaled, tcol);
+                        cols_gather(std::integral_constant<int, 0>{}, op_add, tcol);          // entries already carry the factor r4
 #endif
 #pragma unroll
                         for (int s = 0; s < EPT; s++) {               // tmp = M p (:298), fused p.tmp
