@@ -101,6 +101,7 @@ struct lpbox_solver {
     bool direct = false;          // opt-in direct x-update (lpbox_set_x_update)
     int HL = 0, HLD = 0;
     size_t lds = 0, lds_direct = 0;
+    bool log_on = false; int log_rows = 0; DevBuf<double> logbuf; int log_cap = 0;   // lpbox_set_log: records of the last plain call
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double kernel_ms = 0.0;
@@ -127,7 +128,7 @@ struct lpbox_solver {
         d.rs_ptr = rs_ptr.p; d.rs_col = rs_col.p; d.cs_ptr = cs_ptr.p; d.cs_row = cs_row.p; d.hs_ptr = hs_ptr.p; d.cmeta = cmeta.p; d.rid = rid.p; d.rmeta = rmeta.p; d.rgl = rgl.p;
         d.x = x.p; d.z1 = z1.p; d.z2 = z2.p; d.b = b.p; d.pd = pd.p; d.live = live.p; d.newfix = newfix.p;
         d.z4 = z4.p; d.f = f.p; d.dsc = dsc.p; d.isc = isc.p; d.hist = hist.p;
-        d.ctl = ctl.p; d.dctl = dctl.p; d.xhist = xhist.p; d.ws_cap = ws_cap; d.stamps = stamps.p; d.stamp_wave = getenv("LPBOX_STAMP_WAVE") ? atoi(getenv("LPBOX_STAMP_WAVE")) : 0;
+        d.ctl = ctl.p; d.dctl = dctl.p; d.xhist = xhist.p; d.ws_cap = ws_cap; d.logbuf = nullptr; d.log_cap = 0; d.stamps = stamps.p; d.stamp_wave = getenv("LPBOX_STAMP_WAVE") ? atoi(getenv("LPBOX_STAMP_WAVE")) : 0;
         d.H = direct ? Hinv.p : nullptr; d.HL = direct ? HL : 0; d.HLD = direct ? HLD : 0; d.rdir = rdir.p; d.dng = dng.p;
         return d;
     }
@@ -525,9 +526,11 @@ int finalize(lpbox_t *h) {
     return LPBOX_OK;
 }
 
-int run_window(lpbox_t *h, int iter_start, int iter_end, int l2f) {
+int run_window(lpbox_t *h, int iter_start, int iter_end, int l2f, bool log = false) {
     HIPCHK(hipEventRecord(h->ev0, h->stream));
-    HIPCHK(lp_launch_window(h->dev(), h->T, h->EPT, h->direct ? h->lds_direct : h->lds, iter_start, iter_end, l2f, h->stream, h->direct));
+    LpBatchDev bd = h->dev();
+    if (log) { bd.logbuf = h->logbuf.p; bd.log_cap = h->log_cap; }
+    HIPCHK(lp_launch_window(bd, h->T, h->EPT, h->direct ? h->lds_direct : h->lds, iter_start, iter_end, l2f, h->stream, h->direct, log));
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     int rc = refresh_scalars(h);     // synchronises the stream
     if (rc) return rc;
@@ -638,7 +641,7 @@ void lpbox_destroy(lpbox_t *h) {
     h->rs_col.release(); h->cs_row.release(); h->rid.release(); h->rmeta.release(); h->rgl.release(); h->live_init.release();
     h->x.release(); h->z1.release(); h->z2.release(); h->b.release(); h->pd.release(); h->z4.release(); h->f.release();
     h->f_org.release(); h->dsc.release(); h->hist.release(); h->dctl.release(); h->c1_init.release(); h->xhist.release();
-    h->xi_out.release(); h->live.release(); h->newfix.release(); h->stamps.release(); h->Hinv.release(); h->rdir.release(); h->dng.release();
+    h->xi_out.release(); h->live.release(); h->newfix.release(); h->stamps.release(); h->logbuf.release(); h->Hinv.release(); h->rdir.release(); h->dng.release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -774,8 +777,18 @@ int lpbox_iterate(lpbox_t *h, int iter_start, int iter_end, int *rets) {
     } else {
         HIPCHK(hipMemsetAsync(h->ctl.p, 0, (size_t)h->B * 4 * sizeof(int), h->stream));
     }
-    rc = run_window(h, iter_start, iter_end, rec ? 2 : 0);
+    const bool log = h->log_on && iter_end > iter_start;
+    if (log) {                         // does_log (LPcpp:1013-1067): the values of the reference's per-iteration text log, one record per iteration
+        if (h->direct || !lp_log_supported(h->T, h->EPT)) return fail(LPBOX_E_UNSUPPORTED, "the iteration log is built for the default PCG kernels (512 threads per instance)");
+        const size_t need = (size_t)h->B * (size_t)(iter_end - iter_start) * LP_LOG_VALS;
+        if (need * sizeof(double) > (size_t)1 << 30) return fail(LPBOX_E_UNSUPPORTED, "the iteration log of this call would exceed 1 GiB");
+        if (h->logbuf.count < need) HIPCHK(h->logbuf.alloc(need));
+        h->log_cap = iter_end - iter_start;
+        HIPCHK(hipMemsetAsync(h->logbuf.p, 0xFF, need * sizeof(double), h->stream));      // NaN = iteration not logged (it broke off, or was never reached)
+    }
+    rc = run_window(h, iter_start, iter_end, rec ? 2 : 0, log);
     if (rc) return rc;
+    h->log_rows = log ? iter_end - iter_start : 0;
     if (rec) { h->last_ws = iter_end - iter_start; h->xi_valid = true; h->xi_out_ws = 0; }
     for (int i = 0; i < h->B; i++)
         if (rets) rets[i] = h->h_isc[(size_t)i * NI_COUNT + NI_RET];
@@ -926,6 +939,42 @@ int lpbox_set_record(lpbox_t *h, int on) {
     if (h->seg) return segc_set_record(h->seg, on);
     h->record = on != 0;
     return LPBOX_OK;
+}
+
+// The values of the reference's per-iteration text log (does_log, LPh:148, LPcpp:1013-1067), opt-in: while on, every lpbox_iterate call
+// leaves one record of LPBOX_LOG_VALS doubles per iteration it completed.
+int lpbox_set_log(lpbox_t *h, int on) {
+    if (!valid_handle(h)) return fail(LPBOX_E_BADHANDLE, "bad handle");
+    if (h->seg) return fail(LPBOX_E_UNSUPPORTED, "the segmentation solver of the reference writes no iteration log (SEGh:225)");
+    h->log_on = on != 0;
+    if (!h->log_on) h->log_rows = 0;
+    return LPBOX_OK;
+}
+
+// out[r * LPBOX_LOG_VALS + k], r = 0 .. returned rows - 1: the records of instance idx from the last lpbox_iterate call, in iteration order
+// (iterations that stopped the loop are not logged, as in the reference).  Value 10 is converted to seconds since the call started.
+int lpbox_get_log(lpbox_t *h, int idx, double *out, int cap_rows) {
+    int rc = check_idx(h, idx);
+    if (rc) return rc;
+    if (h->seg) return fail(LPBOX_E_STATE, "this entry point belongs to the LP flavour");
+    if (!out || cap_rows < 0) return fail(LPBOX_E_BADARG, "null output");
+    if (h->log_rows <= 0) return 0;
+    rc = use_device(h);
+    if (rc) return rc;
+    std::vector<double> t((size_t)h->log_rows * LP_LOG_VALS);
+    HIPCHK(hipMemcpy(t.data(), h->logbuf.p + (size_t)idx * h->log_cap * LP_LOG_VALS, t.size() * sizeof(double), hipMemcpyDeviceToHost));
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->device) != hipSuccess || khz <= 0) khz = 100000;
+    int rows = 0;
+    for (int r = 0; r < h->log_rows && rows < cap_rows; r++) {
+        const double *src = &t[(size_t)r * LP_LOG_VALS];
+        if (src[11] != src[11]) continue;                            // NaN: not logged
+        double *dst = out + (size_t)rows * LP_LOG_VALS;
+        for (int k = 0; k < LP_LOG_VALS; k++) dst[k] = src[k];
+        dst[10] = src[10] / (1e3 * khz);
+        rows++;
+    }
+    return rows;
 }
 
 int lpbox_seg_get_x_history(lpbox_t *h, int first, int count, double *out) {

@@ -70,16 +70,23 @@ struct LpBatchDev {
     double *H; int HL, HLD;       // per instance: HL x HLD doubles of H, then LS doubles of W (by row storage index)
     const int16_t *rdir;          // row-task slot -> dense index of its row among the G rows, -1 = D row
     const int *dng;               // G rows per instance
+    // opt-in per-iteration log of the plain loop (lpbox_set_log; what the reference's does_log writes, LPcpp:1013-1067): LP_LOG_VALS doubles
+    // per completed iteration of the call at logbuf[(inst * log_cap + (it - iter_start)) * LP_LOG_VALS]; nullptr = off
+    double *logbuf; int log_cap;
     unsigned long long *stamps;   // diagnostic build only (LPBOX_STAMPS): 16 phase counters per instance, else nullptr
     int stamp_wave;               // ... of this wavefront of the workgroup (LPBOX_STAMP_WAVE, default 0)
 };
+
+// one log record: PCG iterations, |x|, |y1|, |y2|, |y3|, |z1|, |z2|, |z4|, b.x, b.round(x), device wall-clock ticks since the launch started, iteration
+#define LP_LOG_VALS 12
 
 // launchers (lpbox_lp_kernels.hip)
 size_t lp_window_lds_bytes(int T, int NS, int LS, int ZS, int HL = 0, int HLD = 0);   // HL > 0: with the direct mode's dense inverse
 hipError_t lp_launch_init(const LpBatchDev &bd, int T, int EPT, const double *f_org, const double *c1_init,
                           const uint8_t *live_init, hipStream_t s);
 hipError_t lp_launch_window(const LpBatchDev &bd, int T, int EPT, size_t lds, int iter_start, int iter_end, int l2f,
-                            hipStream_t s, bool direct = false);
+                            hipStream_t s, bool direct = false, bool log = false);
+bool lp_log_supported(int T, int EPT);         // geometries the logging variant is compiled for (the default ones: 512 threads)
 bool lp_direct_supported(int T, int EPT);      // geometries the DIRECT variant is compiled for
 hipError_t lp_launch_pack_xiters(const LpBatchDev &bd, const int *live_pos, const int *rows, int ws, double *out,
                                  long out_stride, hipStream_t s);

@@ -414,7 +414,9 @@ struct RowVec {
     }
 };
 
-template <int T, int EPT, typename RCAPS, typename CCAPS, typename HCAPS, bool DIRECT = false>
+// LOG: the plain loop also leaves the reference's per-iteration log values (does_log, LPcpp:1013-1067: six vector norms that nothing else
+// needs) in bd.logbuf -- an instantiation of its own, so the default kernel's code is untouched.
+template <int T, int EPT, typename RCAPS, typename CCAPS, typename HCAPS, bool DIRECT = false, bool LOG = false>
 __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_start, int iter_end, int mode) {
     const int l2f = mode & 1, rec = mode & 2;     // rec: keep x after every iteration in xhist (x_iters of the l2f loop; print_fix_info 2/3 of the plain loop)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -716,6 +718,8 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
         }
 
         int cc = 0;
+        unsigned long long log_t0 = 0;
+        if constexpr (LOG) log_t0 = wall_clock64();
         STAMP_DECL
         for (; it < iter_end; ++it) {
             STAMP(15)
@@ -1037,6 +1041,19 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
                 z4.set(s, rgl(s), rvalid(s), (!l2f && it == iter_start) ? d : z4.get(s, rgl(s), rvalid(s)) + d);   // :920-923 (plain loop overwrites on its first iteration)
             }
             // ---------------- residual norms, objective (:931-1011); the next iteration's first half rides along ----------------
+            double lg[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};            // LOG: |y1|^2 |y2|^2 |y3|^2 |z1|^2 |z2|^2 |z4|^2 of THIS iteration (before prepare() moves y3 on)
+            if constexpr (LOG) {
+#pragma unroll
+                for (int s = 0; s < EPT; s++) {
+                    const double vy3 = y3.get(s, rgl(s), rvalid(s)), vz4 = z4.get(s, rgl(s), rvalid(s));
+                    lg[0] = lg[0] + (live[s] ? y1[s] * y1[s] : 0.0);
+                    lg[1] = lg[1] + (live[s] ? y2[s] * y2[s] : 0.0);
+                    lg[2] = lg[2] + (rvalid(s) ? vy3 * vy3 : 0.0);
+                    lg[3] = lg[3] + (live[s] ? z1.get(s) * z1.get(s) : 0.0);
+                    lg[4] = lg[4] + (live[s] ? z2.get(s) * z2.get(s) : 0.0);
+                    lg[5] = lg[5] + (rvalid(s) ? vz4 * vz4 : 0.0);
+                }
+            }
             const bool rho_step = (it + 1) % LP_RHO_STEP == 0;        // the rho the next iteration will see (:951-970)
             double p5[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
             p5[5] = prepare(rho_step ? learning_fact * rho1 : rho1, rho_step ? learning_fact * rho2 : rho2, rho_step ? learning_fact * rho4 : rho4);
@@ -1052,6 +1069,7 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
             }
             STAMP_POST(12)
             block_sum<T, 6>(p5, red, parity);
+            if constexpr (LOG) block_sum<T, 6>(lg, red, parity);
             pnorm = p5[5];
             STAMP_POST(13)
             {
@@ -1120,6 +1138,15 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
             if (std_obj <= LP_STD_THRESHOLD) { ret = 1; stop = LP_STOP_OBJSTD; break; }   // :977
             cur_obj = p5[4];                                          // :1001-1003
             if (best_bin_obj >= cur_obj) best_bin_obj = cur_obj;
+            if constexpr (LOG) {                                      // the reference logs the iterations that did not break (:1013-1067)
+                if (tid == 0 && bd.logbuf && it - iter_start < bd.log_cap) {
+                    double *lr = bd.logbuf + ((size_t)inst * bd.log_cap + (it - iter_start)) * LP_LOG_VALS;
+                    lr[0] = (double)k_it; lr[1] = sqrt(p5[0]);
+#pragma unroll
+                    for (int k = 0; k < 6; k++) lr[2 + k] = sqrt(lg[k]);
+                    lr[8] = obj_val; lr[9] = cur_obj; lr[10] = (double)(wall_clock64() - log_t0); lr[11] = (double)it;
+                }
+            }
             if constexpr (LEAN) {       // the scalar state is uniform: keep it out of the vector registers across the next iteration
                 rho1 = uniform_f64(rho1); rho2 = uniform_f64(rho2); rho4 = uniform_f64(rho4);
                 prev_rho1 = uniform_f64(prev_rho1); prev_rho2 = uniform_f64(prev_rho2); prev_rho4 = uniform_f64(prev_rho4);
@@ -1188,6 +1215,7 @@ size_t lp_window_lds_bytes(int T, int NS, int LS, int ZS, int HL, int HLD) {
 }
 
 bool lp_direct_supported(int T, int EPT) { return T == 512 && EPT == 1; }     // the default geometry of every n <= 512 batch
+bool lp_log_supported(int T, int EPT) { return T == 512 && (EPT == 1 || EPT == 2 || EPT == 4); }
 
 // (threads, slots per thread) -> per-slot register capacities of the row-task / column gather lists.
 // (512 x 4: the load-balanced deal of lpbox_capi.hip puts each wave's longest block of row tasks / columns into slot 0, so slot 0 alone
@@ -1216,7 +1244,22 @@ hipError_t lp_launch_init(const LpBatchDev &bd, int T, int EPT, const double *f_
 }
 
 hipError_t lp_launch_window(const LpBatchDev &bd, int T, int EPT, size_t lds, int iter_start, int iter_end, int l2f,
-                            hipStream_t s, bool direct) {
+                            hipStream_t s, bool direct, bool log) {
+    if (log) {
+        if (direct || !lp_log_supported(T, EPT) || bd.logbuf == nullptr) return hipErrorInvalidConfiguration;
+#define CALL_LOG(EE, RR, CCC, HHH)                                                                             \
+    {                                                                                                          \
+        auto kfn = lp_window_kernel<512, EE, LP_UNPAREN RR, LP_UNPAREN CCC, LP_UNPAREN HHH, false, true>;      \
+        hipError_t e = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e != hipSuccess) return e;                                                                         \
+        hipLaunchKernelGGL(kfn, dim3(bd.B), dim3(512), lds, s, bd, iter_start, iter_end, l2f);                 \
+    }
+        if (EPT == 1) CALL_LOG(1, (Caps<12>), (Caps<12>), (Caps<8>))
+        else if (EPT == 2) CALL_LOG(2, (Caps<12, 12>), (Caps<12, 8>), (Caps<8, 4>))
+        else CALL_LOG(4, (Caps<12, 8, 8, 8>), (Caps<12, 8, 8, 8>), (Caps<8, 4, 4, 4>))
+#undef CALL_LOG
+        return hipGetLastError();
+    }
     if (direct) {
         if (!lp_direct_supported(T, EPT) || bd.H == nullptr || bd.HL <= 0 || bd.HL > 128) return hipErrorInvalidConfiguration;
 #define CALL_DIRECT(TT)                                                                                        \

@@ -75,6 +75,8 @@ SYMBOLS = {
     "lpbox_kernel_time": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]),
     "lpbox_debug_get_vec": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, _dp, C.c_int]),
     "lpbox_debug_get_scalar": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.POINTER(C.c_double)]),
+    "lpbox_set_log": (C.c_int, [C.c_void_p, C.c_int]),
+    "lpbox_get_log": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_int]),
     "lpbox_big_create": (C.c_void_p, [C.c_int, C.c_int, C.c_int]),
     "lpbox_big_destroy": (None, [C.c_void_p]),
     "lpbox_big_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -17,6 +17,25 @@ def write_xiters_csv(path, X, first_iter=0, mode="w"):
             f.write("Iter%d," % (first_iter + r + 1) + ",".join(map("%f".__mod__, X[r])) + "\n")
 
 
+def write_iteration_log(path, records, stopped_in=None, mode="w"):
+    """The per-iteration text log of ADMM_lp_iters (`does_log`, LPh:148; LPcpp:789, :898-901, :1013-1067; path LPcpp:2496, opened "w+"
+    at :772).  records: (rows, 12) array from lpbox_get_log -- PCG iterations, |x_sol|, |y1|, |y2|, |y3|, |z1|, |z2|, |z4|, dou_obj,
+    bin_obj, seconds, iteration.  stopped_in: the iteration whose stop test ended the loop (its header line is written, its block is
+    not -- the reference breaks before the log block)."""
+    with open(path, mode) as f:
+        for r in np.asarray(records, np.float64).reshape(-1, 12):
+            it = int(r[11])
+            f.write("Iteration: %d\n" % it)
+            f.write("Conjugate gradient stops after %d iterations\n" % int(r[0]))
+            f.write("norm of x_sol: %.9f\nnorm of y1: %.9f\nnorm of y2: %.9f\nnorm of y3: %.9f\n" % (r[1], r[2], r[3], r[4]))
+            f.write("norm of z1: %.9f\nnorm of z2: %.9f\nFor z4\nnorm of z4: %.9f\n" % (r[5], r[6], r[7]))
+            f.write("LongkangIter: %d;  x_sol: %f; dou_obj:%f; bin_obj: %f\n" % (it + 1, r[1], r[8], r[9]))
+            f.write("Time elapsed: %fs\n" % r[10])
+            f.write("-------------------------------------------------\n")
+        if stopped_in is not None:
+            f.write("Iteration: %d\n" % int(stopped_in))
+
+
 def append_allres(path, idx, obj, iters, secs):
     """LP result line "%d,%f,%d,%f" = instance, -objective, iterations, seconds appended to allres.csv (LPcpp:1081)."""
     with open(path, "a") as f:

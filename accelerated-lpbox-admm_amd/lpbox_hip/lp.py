@@ -101,6 +101,17 @@ class LpBatch:
         get_x_iters_2d(j - i)."""
         check(self._L.lpbox_set_record(self._h, 1 if on else 0), "lpbox_set_record")
 
+    def set_log(self, on=True):
+        """The reference's per-iteration log values (does_log, LPcpp:1013-1067), opt-in: solve_iter keeps one record per iteration."""
+        check(self._L.lpbox_set_log(self._h, 1 if on else 0), "lpbox_set_log")
+
+    def get_log(self, idx=0, max_rows=20000):
+        """(rows, 12) records of the last solve_iter call: PCG iterations, |x_sol|, |y1|, |y2|, |y3|, |z1|, |z2|, |z4|, dou_obj, bin_obj,
+        seconds since the call started, iteration."""
+        out = np.zeros((int(max_rows), 12))
+        rows = check(self._L.lpbox_get_log(self._h, _as_int(idx, "idx"), out.ravel(), int(max_rows)), "lpbox_get_log")
+        return out[:rows].copy()
+
     def set_x_update(self, mode="pcg"):
         """How the x-update solves its linear system.  "pcg" (default) is the reference's Jacobi-PCG to 1e-3 (LPcpp:251-335, :894) and
         the only mode that reproduces the reference's iterates.  "direct" is an opt-in WITHOUT reference counterpart: an exact solve
@@ -357,6 +368,7 @@ class PyLPboxADMMsolver:
     """
 
     data_root = None
+    write_log = False        # True: solve_iter writes the reference's per-iteration text log <root>/log/<k>_<j>_log_<i>.txt (LPcpp:1013-1067)
     verbose = False
     # Side-effect files of ADMM_lp_iters (LPcpp:776-783, 903-909, 940-946, 986-992, 1081): <root>/xiter/allres.csv gets one line
     # per plain solve and, for print_info 2/3, <root>/xiter/<k>_<j>_xiters_<i>.csv the iterates.  None: write them iff
@@ -423,13 +435,29 @@ class PyLPboxADMMsolver:
         # instead of staging every iterate of a long call in HBM
         self._final_only = dump and self.print_info == 3 and isinstance(self._b, _LargeInstance)
         self._b.set_record(dump and not self._final_only)
+        log_path = self._log_path() if _as_int(j, "j") > _as_int(i, "i") else None
+        if hasattr(self._b, "set_log"):
+            self._b.set_log(log_path is not None)
         t0 = time.perf_counter()
         ret = int(self._b.solve_iter(i, j)[0])
         secs = int((time.perf_counter() - t0) * 1000) / 1000.0          # the reference truncates to whole ms (LPcpp:1079-1080)
         self._echo_stop(plain=True)
         if out_dir is not None:
             self._write_plain_files(out_dir, int(i), int(j), secs, dump)
+        if log_path is not None:
+            reason, p1 = self._b.stop(0)
+            files.write_iteration_log(log_path, self._b.get_log(0, int(j) - int(i)), stopped_in=p1 - 1 if reason in (1, 2) else None)
         return ret
+
+    def _log_path(self):
+        """<root>/log/<k>_<j>_log_<i>.txt (LPcpp:2496) when `write_log` is set -- the reference writes it by default (does_log = 1, LPh:148);
+        here it is opt-in, and only the on-chip PCG kernels produce it."""
+        if not getattr(self, "write_log", False) or getattr(self, "_file_id", None) is None or not isinstance(self._b, LpBatch):
+            return None
+        d = os.path.join(self._root, "log")
+        os.makedirs(d, exist_ok=True)
+        fi, k, jj = self._file_id
+        return os.path.join(d, "%d_%d_log_%d.txt" % (k, jj, fi))
 
     def _xiter_dir(self):
         if self.write_files is False or getattr(self, "_file_id", None) is None:

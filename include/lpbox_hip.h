@@ -193,6 +193,14 @@ int lpbox_get_row_split(lpbox_t *h, int idx, int *lanes_of_row);
  * help4[4*org_n]; an unsplit column has own[j] = its length and help4 = 0. */
 int lpbox_get_col_split(lpbox_t *h, int idx, int *own, int *help4);
 /* Counters accumulated since init: outer ADMM iterations and PCG iterations of instance idx (LPcpp:894 maxiter). */
+/* The reference's per-iteration text log (does_log, LPh:148, written by ADMM_lp_iters, LPcpp:789, :898-901, :1013-1067), opt-in: while on,
+ * every lpbox_iterate call keeps LPBOX_LOG_VALS doubles per iteration it completed -- PCG iterations, |x_sol|, |y1|, |y2|, |y3|, |z1|, |z2|,
+ * |z4|, b.x ("dou_obj"), b.round(x) ("bin_obj"), seconds since the call started (device clock), iteration -- and lpbox_get_log returns the
+ * records of instance idx in iteration order (rows written; an iteration that stopped the loop is not logged, as in the reference).
+ * Default PCG kernels only (LPBOX_E_UNSUPPORTED otherwise); the Python wrapper formats the text file. */
+#define LPBOX_LOG_VALS 12
+int lpbox_set_log(lpbox_t *h, int on);
+int lpbox_get_log(lpbox_t *h, int idx, double *out, int cap_rows);
 int lpbox_get_counters(lpbox_t *h, int idx, long long *outer_iters, long long *pcg_iters);
 /* Which stop fired in the last call: 0 none, 1 y1_y2, 2 obj_std, 3 PCG alpha<0, 4 all fixed; and iter+1 of the last plain call (LPcpp:1081). */
 int lpbox_get_stop(lpbox_t *h, int idx, int *reason, int *plain_iter_plus1);

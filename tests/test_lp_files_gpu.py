@@ -96,3 +96,44 @@ def test_recording_does_not_change_the_iteration(tmp_path):
     b.solve_iter(0, 400)
     assert np.array_equal(a.batch.debug_vec("x"), b.batch.debug_vec("x"))
     assert np.array_equal(a.get_x_iters_2d(400)[:, -1], b.batch.debug_vec("x"))
+
+
+@pytest.mark.parametrize("fixture,inst,iters", [("lp_100_500_seed0.npz", 0, 20000), ("lp_500_2000_seed0.npz", 2, 300)])
+def test_iteration_log_matches_the_oracles(fixture, inst, iters, tmp_path):
+    """does_log (LPh:148; LPcpp:789, :898-901, :1013-1067): the per-iteration text log the reference writes by default, opt-in here
+    (`write_log`, C-ABI lpbox_set_log / lpbox_get_log: six extra norms per iteration in a logging instantiation of the window kernel).
+    Line for line against the file the oracle writes in the kernels' reduction order: iteration headers, PCG counts and the objective
+    values exactly as printed, the seven norms to the printed nine decimals (the log's norms use Eigen's association in the oracle and
+    the kernel's tree on the GPU: 1e-8 absolute); the elapsed-time lines are not compared.  A full solve (one slot per thread) ends on
+    a stop test, so the trailing header without a block is covered; the j=500/k=2000 instance runs the four-slot variant."""
+    from helpers import lp_instances, oracle_like
+    I = lp_instances(fixture)[inst]
+    g = PyLPboxADMMsolver(0)
+    g.set_problem(I["n"], I["l"], I["colptr"], I["rowidx"], I["b"])
+    g._file_id, g._root, g.write_files, g.write_log = (1, 7, 9), str(tmp_path), False, True
+    g.solve_init()
+    o = oracle_like(g, I)
+    o.set_log(str(tmp_path / "oracle_log.txt"))
+    assert g.solve_iter(0, iters) == o.solve_iter(0, iters)
+    o.set_log(None)
+    got = open(tmp_path / "log" / "7_9_log_1.txt").read().splitlines()
+    want = open(tmp_path / "oracle_log.txt").read().splitlines()
+    assert len(got) == len(want) and len(got) > 12 * min(iters, 200)
+    for a, b in zip(got, want):
+        if a.startswith("Time elapsed"):
+            assert b.startswith("Time elapsed")
+        elif a.startswith("norm of"):
+            ka, va = a.rsplit(": ", 1)
+            kb, vb = b.rsplit(": ", 1)
+            assert ka == kb and abs(float(va) - float(vb)) <= 1e-8, (a, b)
+        elif a.startswith("LongkangIter"):
+            fa, fb = a.replace(";", "").split(), b.replace(";", "").split()
+            assert fa[:2] == fb[:2] and abs(float(fa[3]) - float(fb[3])) <= 1e-5 and fa[4:] == fb[4:], (a, b)
+        else:
+            assert a == b
+    # the log does not perturb the iteration
+    h = PyLPboxADMMsolver(0)
+    h.set_problem(I["n"], I["l"], I["colptr"], I["rowidx"], I["b"])
+    h.solve_init()
+    h.solve_iter(0, iters)
+    assert np.array_equal(h.batch.debug_vec("x").view(np.uint64), g.batch.debug_vec("x").view(np.uint64)) and h.cal_Obj() == g.cal_Obj()
