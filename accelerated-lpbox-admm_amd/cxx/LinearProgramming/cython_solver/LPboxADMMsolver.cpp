@@ -38,6 +38,7 @@ struct LPboxADMMsolver::State {
     bool have_file = false; int file_i = 0, file_k = 0, file_j = 0;
     int org_n = 0, l = 0;
     std::vector<double> xiters, xsol, xfinal, x_prev;
+    bool does_log = false;
     ~State() { if (big) lpbox_big_destroy(big); if (h) lpbox_destroy(h); }
     std::string data_root() const {
         if (!root.empty()) return root;
@@ -136,11 +137,18 @@ inline int LPboxADMMsolver::ADMM_lp_iters_init() {
 inline int LPboxADMMsolver::ADMM_lp_iters(int iter_start, int iter_end) {
     State &s = *s_;
     // side-effect files (LPcpp:776-783, :903-909, :1081): <root>/xiter/allres.csv gets one line per call; print_info 2 / 3 dump the
-    // iterates (on-chip path only).  Written iff <root>/xiter exists (the reference crashes without it).
+    // iterates (both paths; print_info 3 on the large-instance route reads the final iterate back).  Written iff <root>/xiter exists
+    // (the reference crashes without it).  does_log: <root>/log/<k>_<j>_log_<i>.txt iff asked for and <root>/log exists.
     const std::string xdir = s.data_root() + "/xiter";
     const bool files = s.have_file && lpbox_is_dir(xdir);
-    const bool dump = files && !s.big && (s.print_info == 2 || s.print_info == 3) && iter_end > iter_start;
+    const bool dump = files && (s.print_info == 2 || s.print_info == 3) && iter_end > iter_start;
+    // print_info 3 writes only the iterate of the stop (LPcpp:940-946): on the large-instance route it is read back after the solve
+    const bool final_only = dump && s.big && s.print_info == 3;
     if (!s.big) lpbox_ok(lpbox_set_record(s.h, dump ? 1 : 0), "lpbox_set_record");
+    else lpbox_ok(lpbox_big_set_record(s.big, dump && !final_only ? 1 : 0), "lpbox_big_set_record");
+    const std::string ldir = s.data_root() + "/log";
+    const bool log = s.does_log && !s.big && s.have_file && iter_end > iter_start && lpbox_is_dir(ldir);
+    if (!s.big) lpbox_ok(lpbox_set_log(s.h, log ? 1 : 0), "lpbox_set_log");
     const auto t0 = std::chrono::steady_clock::now();
     int ret = 0;
     if (s.big) lpbox_ok(lpbox_big_iterate(s.big, iter_start, iter_end, &ret), "lpbox_big_iterate");
@@ -150,12 +158,29 @@ inline int LPboxADMMsolver::ADMM_lp_iters(int iter_start, int iter_end) {
     if (files) {
         int p1 = 0;
         const int reason = s.stop(&p1);
-        if (dump) {
+        if (final_only) {
+            if (reason == 1 || reason == 2) {
+                char name[64];
+                snprintf(name, sizeof name, "/%d_%d_xiters_%d.csv", s.file_k, s.file_j, s.file_i);
+                if (FILE *xi = fopen((xdir + name).c_str(), "w+")) {
+                    const double *x = get_final_x_sol();
+                    const int rows = get_n();
+                    fprintf(xi, "Iter%d,", p1);
+                    for (int r = 0; r < rows; r++) fprintf(xi, r + 1 < rows ? "%lf," : "%lf", x[r]);
+                    fprintf(xi, "\n");
+                    fclose(xi);
+                }
+            }
+        } else if (dump) {
             const int ws = iter_end - iter_start;
             const int done = (reason == 1 || reason == 2) ? p1 - iter_start : ws;
-            const int rows = lpbox_ok(lpbox_get_x_iters(s.h, 0, ws, nullptr), "lpbox_get_x_iters");
+            const int rows = s.big ? lpbox_ok(lpbox_big_get_x_iters(s.big, ws, nullptr), "lpbox_big_get_x_iters")
+                                   : lpbox_ok(lpbox_get_x_iters(s.h, 0, ws, nullptr), "lpbox_get_x_iters");
             std::vector<double> X((size_t)rows * ws);
-            if (rows) lpbox_ok(lpbox_get_x_iters(s.h, 0, ws, X.data()), "lpbox_get_x_iters");
+            if (rows) {
+                if (s.big) lpbox_ok(lpbox_big_get_x_iters(s.big, ws, X.data()), "lpbox_big_get_x_iters");
+                else lpbox_ok(lpbox_get_x_iters(s.h, 0, ws, X.data()), "lpbox_get_x_iters");
+            }
             const int lo = s.print_info == 2 ? 0 : ((reason == 1 || reason == 2) ? done - 1 : done);
             char name[64];
             snprintf(name, sizeof name, "/%d_%d_xiters_%d.csv", s.file_k, s.file_j, s.file_i);
@@ -173,8 +198,33 @@ inline int LPboxADMMsolver::ADMM_lp_iters(int iter_start, int iter_end) {
             fclose(al);
         }
     }
+    if (log) {                                                       // LPcpp:772 ("w+"), :789, :898-901, :1013-1067
+        int p1 = 0;
+        const int reason = s.stop(&p1);
+        const int ws = iter_end - iter_start;
+        std::vector<double> rec((size_t)ws * LPBOX_LOG_VALS);
+        const int rows = lpbox_ok(lpbox_get_log(s.h, 0, rec.data(), ws), "lpbox_get_log");
+        char name[64];
+        snprintf(name, sizeof name, "/%d_%d_log_%d.txt", s.file_k, s.file_j, s.file_i);
+        if (FILE *fp = fopen((ldir + name).c_str(), "w+")) {
+            for (int r = 0; r < rows; r++) {
+                const double *v = &rec[(size_t)r * LPBOX_LOG_VALS];
+                fprintf(fp, "Iteration: %d\n", (int)v[11]);
+                fprintf(fp, "Conjugate gradient stops after %d iterations\n", (int)v[0]);
+                fprintf(fp, "norm of x_sol: %.9lf\nnorm of y1: %.9lf\nnorm of y2: %.9lf\nnorm of y3: %.9lf\n", v[1], v[2], v[3], v[4]);
+                fprintf(fp, "norm of z1: %.9lf\nnorm of z2: %.9lf\nFor z4\nnorm of z4: %.9lf\n", v[5], v[6], v[7]);
+                fprintf(fp, "LongkangIter: %d;  x_sol: %lf; dou_obj:%lf; bin_obj: %lf\n", (int)v[11] + 1, v[1], v[8], v[9]);
+                fprintf(fp, "Time elapsed: %lfs\n", v[10]);
+                fprintf(fp, "-------------------------------------------------\n");
+            }
+            if (reason == 1 || reason == 2) fprintf(fp, "Iteration: %d\n", p1 - 1);
+            fclose(fp);
+        }
+    }
     return ret;
 }
+
+inline void LPboxADMMsolver::set_does_log(int on) { s_->does_log = on != 0; }
 
 inline int LPboxADMMsolver::ADMM_lp_iters_l2f(int iter_start, int iter_end, double *vec, int num) {
     State &s = *s_;

@@ -42,6 +42,8 @@ public:
     int check_infeasible_l2f();                               // lpbox_check_infeasible_l2f LPcpp:1593-1612
     void set_fix_threshold(double t);                         // LPh:365-367
     void set_consistency(int c);                              // LPh:369-371
+    void set_does_log(int on);                                // the per-iteration text log <root>/log/<k>_<j>_log_<i>.txt (LPh:148: ON by default in the
+                                                              // reference; OFF here until asked for; lpbox_set_log / lpbox_get_log, on-chip path)
 
     // ---- not in the reference ----
     void set_problem(int n, int l, const int *colptr, const int *rowidx, const double *b, const double *f = nullptr);   // lpbox_set_problem_lp

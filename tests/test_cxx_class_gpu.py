@@ -98,6 +98,50 @@ def test_cxx_side_effect_files_equal_python(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cxx_iteration_log_and_large_route_dump_equal_python(tmp_path):
+    """(1) does_log (LPcpp:1013-1067): the C++ class writes <root>/log/<k>_<j>_log_<i>.txt like the Python wrapper (whose lines are held
+    against the oracle's log in tests/test_lp_files_gpu.py): same bytes except the elapsed-time lines.  (2) print_info 2 on an instance
+    beyond the on-chip kernel: the iterate dump of the large-instance route, same bytes as the Python wrapper's."""
+    import shutil
+    from lpbox_hip.lp import PyLPboxADMMsolver
+    from lpbox_hip.synth import make_auction_like, write_instance_files
+    exe = build_driver(tmp_path)
+    roots = []
+    for name in ("cxx", "py"):
+        root = tmp_path / name
+        os.makedirs(root / "instance" / "100_500")
+        os.makedirs(root / "log")
+        for f in ("instance_1_C.txt", "instance_1_b.txt"):
+            shutil.copy(os.path.join(GOLDEN, "instance", "100_500", f), root / "instance" / "100_500" / f)
+        roots.append(root)
+    run_driver(exe, roots[0], 1, 100, 500, 20000, 0, 0, 1)
+    g = PyLPboxADMMsolver(0)
+    g.data_root, g.write_files, g.write_log = str(roots[1]), False, True
+    g.read_File(1, 100, 500)
+    g.solve_init()
+    g.solve_iter(0, 20000)
+    a = [ln for ln in open(roots[0] / "log" / "100_500_log_1.txt") if not ln.startswith("Time elapsed")]
+    b = [ln for ln in open(roots[1] / "log" / "100_500_log_1.txt") if not ln.startswith("Time elapsed")]
+    assert a == b and len(a) > 50000 and a[-1].startswith("Iteration: ")
+    P = make_auction_like(2300, 7)
+    for root in roots:
+        d = root / "instance" / "1000_2300"
+        os.makedirs(d)
+        os.makedirs(root / "xiter")
+        write_instance_files(P, str(d / "instance_1_C.txt"), str(d / "instance_1_b.txt"))
+    res, _ = run_driver(exe, roots[0], 1, 1000, 2300, 25, 0, 2)
+    assert int(res["large"]) == 1
+    h = PyLPboxADMMsolver(2)
+    h.data_root = str(roots[1])
+    h.read_File(1, 1000, 2300)
+    h.solve_init()
+    h.solve_iter(0, 25)
+    assert h.large
+    xa = open(roots[0] / "xiter" / "1000_2300_xiters_1.csv").read()
+    assert xa == open(roots[1] / "xiter" / "1000_2300_xiters_1.csv").read() and xa.count("\n") == 25
+
+
+@pytest.mark.gpu
 def test_cxx_rule_based_fixing_equals_python(tmp_path):
     """ADMM_lp_iters_fix through the C++ class (LPcpp:1689-2286, repaired semantics of DESIGN.md section 16) takes the decisions of
     PyLPboxADMMsolver.solve_iter_fix, which tests/test_lp_fix_rule_gpu.py holds against the oracle: same fixes, same end state."""
