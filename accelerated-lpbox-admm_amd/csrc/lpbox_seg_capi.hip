@@ -178,7 +178,7 @@ void build_costs(const unsigned char *gray, int rows, int cols, std::vector<int>
 // Can the matrix be held as diagonals (SegDev::dia)?  At most three distinct column offsets either side of the main diagonal, a stored
 // diagonal entry in every row, every off-diagonal value equal to -w for an integer w in 0..255.  True for every problem the image cost
 // builder makes (SEGcpp:144-248: offsets {+-1, +-(ncols-1), +-ncols}, w = round(3 exp(.))); anything else keeps the ELL form.
-bool as_diagonals(const SegSolver *s, std::vector<unsigned long long> &dpack, std::vector<double> &adiag) {
+bool as_diagonals(const SegSolver *s, int (&doff)[7], std::vector<unsigned long long> &dpack, std::vector<double> &adiag) {
     const int n = s->n;
     std::vector<int> neg, pos;
     auto note = [](std::vector<int> &v, int off) {
@@ -199,7 +199,6 @@ bool as_diagonals(const SegSolver *s, std::vector<unsigned long long> &dpack, st
         if (!have_diag) return false;
     }
     std::sort(neg.begin(), neg.end()); std::sort(pos.begin(), pos.end());
-    int *doff = const_cast<SegSolver *>(s)->doff;
     // slots 0..2: negative offsets ascending (missing ones in front), 3: the diagonal, 4..6: positive ascending (missing ones behind);
     // a missing slot points at a harmless neighbour and carries w = 0 in every row
     for (int k = 0; k < 3; k++) doff[k] = -1, doff[4 + k] = 1;
@@ -234,7 +233,7 @@ int upload(SegSolver *s) {
     if (w > 255) return lpbox_fail(LPBOX_E_UNSUPPORTED, "a row of A stores %d entries; the ELL layout of the segmentation kernels holds at most 255", w);
     s->ell_w = w;
     std::vector<unsigned long long> dpack; std::vector<double> adiag;
-    s->dia = n >= 2 && w <= 7 && !getenv("LPBOX_SEG_NODIA") && as_diagonals(s, dpack, adiag);      // LPBOX_SEG_NODIA: keep ELL (A/B, tests)
+    s->dia = n >= 2 && w <= 7 && !getenv("LPBOX_SEG_NODIA") && as_diagonals(s, s->doff, dpack, adiag);      // LPBOX_SEG_NODIA: keep ELL (A/B, tests)
     if (s->dia) {
         s->d_ecol.release(); s->d_eval.release();
         HIPCHK(s->d_dpack.alloc(n)); HIPCHK(s->d_adiag.alloc(n));

@@ -231,11 +231,32 @@ def self_launch(args, argv):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out)
+    # a rank that dies early would leave the others waiting in the rendezvous or a barrier: watch all of them, and if one fails
+    # stop the rest instead of hanging until a collective times out
+    import threading
+    out_chunks = []
+    reader = threading.Thread(target=lambda: out_chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0):
+                failed = r
+        time.sleep(0.2)
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        sys.stderr.write(f"bench.py: rank {failed} exited with code {procs[failed].returncode}; the other ranks were stopped\n")
+    reader.join(timeout=10)
+    sys.stdout.write("".join(c for c in out_chunks if c))
     sys.stdout.flush()
-    return max(abs(rc) for rc in rcs)
+    return max(abs(p.returncode or 0) for p in procs) if failed is None else (abs(procs[failed].returncode) or 1)
 
 
 def main(argv=None):
@@ -255,6 +276,8 @@ def main(argv=None):
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args, argv)
     rank, local_rank, world = dist_setup(args)
+    if os.environ.get("LPBOX_BENCH_FAIL_RANK") == str(rank) and STUB:           # test hook (tests/test_bench_launch.py): a rank that dies at start
+        raise SystemExit(3)
     headline = args.config or 2
     extras = [] if (args.config is not None or world > 1 or args.no_extra_configs or STUB) else [4, 3, 5]
 

@@ -69,3 +69,14 @@ def test_world_size_mismatch_is_refused():
                          env=_env(RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="1"),
                          capture_output=True, text=True, timeout=120)
     assert out.returncode != 0 and "WORLD_SIZE=2" in out.stderr
+
+
+def test_a_failing_rank_stops_the_others_instead_of_hanging():
+    """Rank 1 dies before the rendezvous (LPBOX_BENCH_FAIL_RANK, test hook): the parent must stop rank 0 and return non-zero quickly."""
+    import time
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "4", "--config", "2"],
+                         env=_env(LPBOX_BENCH_FAIL_RANK="1"), capture_output=True, text=True, timeout=240)
+    assert out.returncode != 0 and "rank 1 exited" in out.stderr
+    assert time.time() - t0 < 200
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
