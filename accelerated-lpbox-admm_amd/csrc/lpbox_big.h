@@ -64,6 +64,12 @@ struct BigDev {
     // and every consumer runs rank r's tree over its Gr[r] partials, then adds the W totals in rank order (what big_k_rank_sum did).
     int fold, W, gathered, Gs, Gr[BIG_MAXW];      // gathered: the consumers read gpart (W > 1, or an RCCL communicator of one rank)
     const double *gpart;
+    // opt-in COMM-LEAN PCG (lpbox_big_set_pcg_mode; NOT the reference's arithmetic): the step length comes from
+    // p.Mp = dI (p.p) + r4Et (q.q), q = E p.  p.p partials (one per column workgroup) and q.q partials (one per row workgroup: of the
+    // row gather on one rank, of the rank's row block otherwise) sit in lsmall[0 .. Gs) and lsmall[Gs .. Gs + Gqs); with W > 1 they ride
+    // with the q exchange into gsmall[rank][Gs + Gqs].  pcg_cols and pcg_upd become ONE kernel, the p.Mp exchange disappears.
+    int lean, Gq, Gqs, Gqr[BIG_MAXW];
+    double *lsmall; const double *gsmall;
     BigState *st;                         // st[0], st[1]
 };
 
@@ -83,6 +89,8 @@ hipError_t big_launch_rows(const BigDev &d, int mode, int *parity, hipStream_t s
 hipError_t big_launch_resid(const BigDev &d, int *parity, hipStream_t s);
 hipError_t big_launch_pcg_cols(const BigDev &d, int *parity, hipStream_t s);
 hipError_t big_launch_pcg_upd(const BigDev &d, int *parity, hipStream_t s);
+hipError_t big_launch_pcg_lean(const BigDev &d, int *parity, hipStream_t s);          // comm-lean mode: tmp = M p, alpha from p.p and q.q, x / r / z updates, partials (r.r, r.z)
+hipError_t big_launch_rank_sum_qq(const double *g, int W, long count, long stride, double *out, double *qq_part, hipStream_t s);   // rank-ordered sum of a row block + q.q partials per 256 rows
 hipError_t big_launch_post(const BigDev &d, int *parity, hipStream_t s);              // duals z1,z2, partials(5), gsrc = x
 hipError_t big_launch_z4(const BigDev &d, int init_only, int *parity, hipStream_t s); // Ex = q [, z4 update]
 hipError_t big_launch_resume(const BigDev &d, int reset_pcg_max, int *parity, hipStream_t s);

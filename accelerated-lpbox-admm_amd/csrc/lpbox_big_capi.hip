@@ -83,6 +83,9 @@ struct lpbox_big {
     int G = 0, Gl = 0, EPT = 2, EPTl = 2, P = 1, Glr = 0, kmax = 28, parity = 0;
     bool fold = false; int Gs = 0, Gr[BIG_MAXW] = {0};        // folded reductions (BigDev::fold): partial stride, workgroups of every rank
     Buf<double> gpart;                                          // W > 1, folded: the gathered partials [phase][rank][nv][Gs]
+    bool lean = false;                                          // lpbox_big_set_pcg_mode(LPBOX_PCG_COMM_LEAN), before lpbox_big_init
+    int Gq = 0, Gqs = 0, Gqr[BIG_MAXW] = {0};                   // q.q partials: of this rank, stride, of every rank (BigDev::Gq)
+    Buf<double> lsmall, gsmall;
     bool adaptive = true;
     int kmargin = 1;                                            // spare PCG launch groups beyond the largest count of the previous batch (LPBOX_BIG_KMARGIN)
     double kernel_ms = 0.0; long long launches = 0, collectives = 0;
@@ -108,7 +111,8 @@ struct lpbox_big {
         d.zp = zp.p; d.xt = xt.p; d.live = live.p; d.newfix = newfix.p; d.xhist = xhist.p; d.ws_cap = ws_cap;
         d.y3 = y3.p; d.z4 = z4.p; d.f = df.p; d.fz = fz.p; d.Ex = Ex.p; d.q = q.p; d.part = part.p; d.red = red.p; d.st = st.p;
         d.fold = fold ? 1 : 0; d.W = world; d.Gs = Gs; d.gpart = gpart.p; d.gathered = gpart.p != nullptr;
-        for (int r = 0; r < BIG_MAXW; r++) d.Gr[r] = Gr[r];
+        for (int r = 0; r < BIG_MAXW; r++) { d.Gr[r] = Gr[r]; d.Gqr[r] = Gqr[r]; }
+        d.lean = lean ? 1 : 0; d.Gq = Gq; d.Gqs = Gqs; d.lsmall = lsmall.p; d.gsmall = gsmall.p;
         return d;
     }
 };
@@ -192,7 +196,51 @@ int gather_partials(lpbox_big *h, const BigDev &d, int phase, int nv) {
 #define FINX(nv) do { HIPCHK(big_launch_fin(d, nv, BIG_PH_X, h->stream)); h->launches++; CHK(allreduce(h, d.red + BIG_PH_X * BIG_NPART, nv)); } while (0)
 #define ROWS(mode) do { HIPCHK(big_launch_rows(d, mode, &h->parity, h->stream)); h->launches++; CHK(allreduce(h, d.q, h->l)); } while (0)
 
+// comm-lean PCG, W > 1: the q exchange of allreduce() with the scalars riding along -- the row blocks go to their owners (one grouped
+// send/recv), the owner adds its block in rank order and squares it (big_k_rank_sum_qq: q.q partials behind the p.p partials the row
+// kernel left in lsmall), then ONE grouped all-gather brings back the reduced blocks and everybody's partials.
+int exchange_q_lean(lpbox_big *h, const BigDev &d) {
+    const int W = h->world;
+    const long lb = ((long)h->l + W - 1) / W;
+    const long lo = std::min<long>((long)h->rank * lb, h->l), mine = std::min<long>(lb, h->l - lo);
+    const size_t small = (size_t)h->Gs + h->Gqs;
+    if (h->comm) {
+        NCCLCHK(g_rccl.GroupStart());
+        for (int pr = 0; pr < W; pr++) {
+            NCCLCHK(g_rccl.Send(h->q.p + (long)pr * lb, (size_t)lb, ncclDouble, pr, h->comm, h->stream));
+            NCCLCHK(g_rccl.Recv(h->gath.p + (long)pr * lb, (size_t)lb, ncclDouble, pr, h->comm, h->stream));
+        }
+        NCCLCHK(g_rccl.GroupEnd());
+        HIPCHK(big_launch_rank_sum_qq(h->gath.p, W, mine, lb, h->q.p + (long)h->rank * lb, h->lsmall.p + h->Gs, h->stream));
+        NCCLCHK(g_rccl.GroupStart());
+        NCCLCHK(g_rccl.AllGather(h->q.p + (long)h->rank * lb, h->q.p, (size_t)lb, ncclDouble, h->comm, h->stream));
+        NCCLCHK(g_rccl.AllGather(h->lsmall.p, h->gsmall.p, small, ncclDouble, h->comm, h->stream));
+        NCCLCHK(g_rccl.GroupEnd());
+        h->collectives += 2;
+        return LPBOX_OK;
+    }
+    if (!h->ag) return lpbox_fail(LPBOX_E_STATE, "world = %d but neither an RCCL communicator nor an all-gather callback was set", W);
+    // callback transport (tests): whole contributions are gathered, every rank adds all rows in rank order; only its own block's squares count
+    int rc = h->ag(h->q.p, h->l, h->gath.p, h->ag_user);
+    if (rc != 0) return lpbox_fail(LPBOX_E_HIP, "all-gather callback failed (%d)", rc);
+    HIPCHK(big_launch_rank_sum(h->gath.p, W, h->l, h->l, h->q.p, h->stream));
+    HIPCHK(big_launch_rank_sum_qq(h->gath.p + lo, W, mine, h->l, h->q.p + lo, h->lsmall.p + h->Gs, h->stream));
+    rc = h->ag(h->lsmall.p, (long)small, h->gsmall.p, h->ag_user);
+    if (rc != 0) return lpbox_fail(LPBOX_E_HIP, "all-gather callback failed (%d)", rc);
+    h->collectives += 2;
+    return LPBOX_OK;
+}
+
 int enqueue_pcg(lpbox_big *h, const BigDev &d, int pairs) {
+    if (h->lean) {
+        for (int k = 0; k < pairs; k++) {
+            HIPCHK(big_launch_rows(d, 1, &h->parity, h->stream)); h->launches++;
+            if (h->world > 1 || h->comm) CHK(exchange_q_lean(h, d));
+            HIPCHK(big_launch_pcg_lean(d, &h->parity, h->stream)); h->launches++;
+            FIN(2, BIG_PH_D);
+        }
+        return LPBOX_OK;
+    }
     for (int k = 0; k < pairs; k++) {
         ROWS(1);
         HIPCHK(big_launch_pcg_cols(d, &h->parity, h->stream)); h->launches++;
@@ -279,7 +327,7 @@ void lpbox_big_destroy(lpbox_big_t *h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->d_rptr.release(); h->d_rcol.release(); h->d_cptr.release(); h->d_crow.release();
     for (Buf<double> *bp : {&h->x, &h->y1, &h->y2, &h->z1, &h->z2, &h->db, &h->pd, &h->dinv, &h->rhs, &h->r, &h->z, &h->tmp, &h->p0, &h->p1,
-                            &h->gsrc, &h->y3, &h->z4, &h->df, &h->Ex, &h->q, &h->part, &h->red, &h->xt, &h->xhist, &h->xi_out, &h->gath, &h->flag, &h->gpart})
+                            &h->gsrc, &h->y3, &h->z4, &h->df, &h->Ex, &h->q, &h->part, &h->red, &h->xt, &h->xhist, &h->xi_out, &h->gath, &h->flag, &h->gpart, &h->lsmall, &h->gsmall})
         bp->release();
     for (auto &kv : h->gexec) (void)hipGraphExecDestroy(kv.second);
     for (hipGraph_t g : h->graphs) (void)hipGraphDestroy(g);
@@ -304,6 +352,17 @@ int lpbox_big_set_stream(lpbox_big_t *h, void *hip_stream) {
 int lpbox_big_set_record(lpbox_big_t *h, int on) {
     if (!h) return lpbox_fail(LPBOX_E_BADHANDLE, "bad handle");
     h->record = on != 0;
+    return LPBOX_OK;
+}
+
+// Opt-in, NOT the reference's arithmetic: the PCG's step length from p.Mp = dI (p.p) + r4Et (q.q) with q = E p, which
+// lets the p.p partials ride with the q exchange and fuses the column product with the vector updates -- 3 instead of 4 RCCL operations and
+// 2 instead of 3 kernels per PCG iteration.  Before lpbox_big_init; needs the folded reductions (<= 1024 workgroups, <= 16 ranks).
+int lpbox_big_set_pcg_mode(lpbox_big_t *h, int mode) {
+    if (!h) return lpbox_fail(LPBOX_E_BADHANDLE, "bad handle");
+    if (h->inited) return lpbox_fail(LPBOX_E_STATE, "set the PCG mode before lpbox_big_init");
+    if (mode != LPBOX_PCG_REFERENCE && mode != LPBOX_PCG_COMM_LEAN) return lpbox_fail(LPBOX_E_BADARG, "unknown PCG mode %d", mode);
+    h->lean = mode == LPBOX_PCG_COMM_LEAN;
     return LPBOX_OK;
 }
 
@@ -431,6 +490,19 @@ int lpbox_big_init(lpbox_big_t *h) {
         HIPCHK(h->fz.alloc(l));
         HIPCHK(h->q.alloc((size_t)h->q_cap)); HIPCHK(hipMemset(h->q.p, 0, sizeof(double) * (size_t)h->q_cap));
         HIPCHK(h->part.alloc((size_t)BIG_PH_COUNT * BIG_NPART * h->Gs)); HIPCHK(h->red.alloc(BIG_PH_COUNT * BIG_NPART)); HIPCHK(h->st.alloc(2));
+        if (h->lean) {
+            if (!h->fold) return lpbox_fail(LPBOX_E_UNSUPPORTED, "the comm-lean PCG needs the folded reductions (at most 1024 workgroups per rank, 16 ranks)");
+            const int W = h->world;
+            const long lb = ((long)l + W - 1) / W;
+            const bool xch = W > 1 || h->comm;              // the q exchange runs (also against a one-rank communicator: tests)
+            if (xch) {
+                for (int r = 0; r < W; r++) { const long lo = std::min<long>((long)r * lb, l), cnt = std::min<long>(lb, l - lo); h->Gqr[r] = (int)((cnt + BIG_T - 1) / BIG_T); }
+                h->Gq = h->Gqr[h->rank]; h->Gqs = (int)((lb + BIG_T - 1) / BIG_T);
+            } else { h->Gq = h->P > 1 ? h->Glr : h->Gl; h->Gqs = h->Gq; h->Gqr[0] = h->Gq; }
+            if (h->Gq > 8 * BIG_T) return lpbox_fail(LPBOX_E_UNSUPPORTED, "the comm-lean PCG sums at most %d row-workgroup partials per rank", 8 * BIG_T);
+            HIPCHK(h->lsmall.alloc((size_t)h->Gs + h->Gqs)); HIPCHK(hipMemset(h->lsmall.p, 0, sizeof(double) * ((size_t)h->Gs + h->Gqs)));
+            if (xch) { HIPCHK(h->gsmall.alloc((size_t)W * ((size_t)h->Gs + h->Gqs))); HIPCHK(hipMemset(h->gsmall.p, 0, sizeof(double) * (size_t)W * ((size_t)h->Gs + h->Gqs))); }
+        }
         if (h->fold && (h->world > 1 || h->comm)) {         // (a one-rank RCCL communicator runs the exchange against itself: tests)
             HIPCHK(h->gpart.alloc((size_t)BIG_PH_COUNT * h->world * BIG_NPART * h->Gs));
             HIPCHK(hipMemset(h->gpart.p, 0, sizeof(double) * (size_t)BIG_PH_COUNT * h->world * BIG_NPART * h->Gs));
@@ -702,7 +774,8 @@ int lpbox_big_get_scalar(lpbox_big_t *h, const char *name, double *out) {
         {"sum_fix_obj", s.sum_fix_obj}, {"fix_obj", s.fix_obj}, {"c1", s.c1}, {"ret", (double)s.ret}, {"n_live", (double)h->n_live_glob},
         {"stop", (double)s.stop}, {"plain_iter_p1", (double)s.plain_iter_p1}, {"kmax", (double)h->kmax},
         {"launches", (double)h->launches}, {"collectives", (double)h->collectives}, {"kernel_ms", h->kernel_ms},
-        {"threads", (double)BIG_T}, {"chunk", (double)(BIG_T * h->EPT)}, {"groups", (double)h->G}, {"row_slices", (double)h->P}, {"folded_reductions", h->fold ? 1.0 : 0.0},
+        {"threads", (double)BIG_T}, {"chunk", (double)(BIG_T * h->EPT)}, {"groups", (double)h->G}, {"row_slices", (double)h->P}, {"folded_reductions", h->fold ? 1.0 : 0.0}, {"pcg_comm_lean", h->lean ? 1.0 : 0.0},
+        {"row_chunk", (double)((h->world > 1 || h->comm) ? BIG_T : (h->P > 1 ? BIG_T : BIG_T * h->EPTl))},
     };
     for (auto &e : tab) if (!strcmp(e.n, name)) { *out = e.v; return LPBOX_OK; }
     return lpbox_fail(LPBOX_E_BADARG, "unknown scalar '%s'", name);

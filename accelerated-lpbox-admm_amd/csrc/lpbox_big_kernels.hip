@@ -386,11 +386,41 @@ __global__ void __launch_bounds__(T) big_k_rows(BigDev d, int in, int out, int m
     } else forward_state(d, in, out);
     const double *gs = d.gsrc, *p0 = d.p0;
     (void)pold;
+    const bool lean = d.lean && mode == 1;
+    const int rowgrid = d.P > 1 ? d.Glr : d.Gl;
+    if (lean && (int)blockIdx.x < d.G) {
+        // comm-lean PCG: the search direction p = z + beta p of this iteration for the workgroup's own variables (what pcg_cols does in the
+        // default mode) and the workgroup partial of p.p, which rides with the q exchange
+        const int k = si->pcg_k;
+        double *pnew = (k & 1) ? d.p1 : d.p0;
+        double pp[1] = {0.0};
+        for (int q = 0; q < d.EPT; q++) {
+            const int j = blockIdx.x * (T * d.EPT) + q * T + threadIdx.x;
+            double c = 0.0;
+            if (j < d.n_loc) {
+                double pj;
+                if (first) pj = p0[j];
+                else { pj = d.z[j] + beta * pold[j]; pnew[j] = pj; }                // p = z + beta p (:319)
+                c = d.live[j] ? pj * pj : 0.0;
+            }
+            pp[0] = pp[0] + c;
+        }
+        block_sum<T, 1>(pp, red, parity);
+        if (threadIdx.x == 0) d.lsmall[blockIdx.x] = pp[0];
+    }
+    if ((int)blockIdx.x >= rowgrid) return;
+    const bool lean_qq = lean && !d.gathered;        // no exchange: q is final here, so its squares are summed here too
+    double qq[1] = {0.0};
     if (d.P > 1) {                                   // column-sliced rows (see row_sum_sliced): one row per thread
         const int i = blockIdx.x * T + threadIdx.x;
-        if (i >= d.l) return;
-        if (mode == 0 || first) d.q[i] = row_sum_sliced<false>(d, i, mode == 0 ? gs : p0, nullptr, 0.0);
-        else d.q[i] = row_sum_sliced<true>(d, i, nullptr, d.zp, beta);
+        if (i < d.l) {
+            double qi;
+            if (mode == 0 || first) qi = row_sum_sliced<false>(d, i, mode == 0 ? gs : p0, nullptr, 0.0);
+            else qi = row_sum_sliced<true>(d, i, nullptr, d.zp, beta);
+            d.q[i] = qi;
+            qq[0] = qq[0] + qi * qi;
+        }
+        if (lean_qq) { block_sum<T, 1>(qq, red, parity); if (threadIdx.x == 0) d.lsmall[d.Gs + blockIdx.x] = qq[0]; }
         return;
     }
     for (int s = 0; s < d.EPTl; s++) {
@@ -426,7 +456,9 @@ __global__ void __launch_bounds__(T) big_k_rows(BigDev d, int in, int out, int m
             for (; k < k1; k++) { const double2 v = d.zp[d.rcol[k]]; acc += v.x + beta * v.y; }
         }
         d.q[i] = acc;
+        qq[0] = qq[0] + acc * acc;
     }
+    if (lean_qq) { block_sum<T, 1>(qq, red, parity); if (threadIdx.x == 0) d.lsmall[d.Gs + blockIdx.x] = qq[0]; }
 }
 
 __global__ void __launch_bounds__(T) big_k_resid(BigDev d, int in, int out) {       // :267-294
@@ -546,6 +578,101 @@ __global__ void __launch_bounds__(T) big_k_pcg_upd(BigDev d, int in, int out) { 
         if (fail) { d.st[out].pcg_done = 1; d.st[out].stop = LP_STOP_PCG; }
         else d.st[out].pcg_k = k + 1;
     }
+}
+
+// COMM-LEAN PCG (opt-in, not the reference's arithmetic): pcg_cols and pcg_upd in one launch.  p.Mp is not summed over the variables but
+// taken from p.p and q.q -- both complete once the q exchange is: alpha = absNew / (dI (p.p) + r4Et (q.q)) -- so no exchange separates the
+// column product from the vector updates.  Totals: per rank the tree over its workgroup partials, the rank totals in rank order.
+constexpr int FOLD_UQ = 8;     // q.q partials per thread (one rank: up to 2048 row workgroups)
+__device__ __forceinline__ double lean_total(const BigDev &d, bool qq, double *red, int &parity) {
+    const int W = d.W > 1 ? d.W : 1;
+    double out = 0.0;
+    for (int r = 0; r < W; r++) {
+        const double *base = (d.gathered ? d.gsmall + (size_t)r * (d.Gs + d.Gqs) : d.lsmall) + (qq ? d.Gs : 0);
+        const int G = qq ? (d.gathered ? d.Gqr[r] : d.Gq) : (d.gathered ? d.Gr[r] : d.G);
+        double t[FOLD_UQ];
+#pragma unroll
+        for (int u = 0; u < FOLD_UQ; u++) { const int e = threadIdx.x + u * T; t[u] = e < G ? base[e] : 0.0; }
+        double a[1] = {0.0};
+#pragma unroll
+        for (int u = 0; u < FOLD_UQ; u++) a[0] = (int)threadIdx.x + u * T < G ? a[0] + t[u] : a[0];
+        block_sum<T, 1>(a, red, parity);
+        out = r == 0 ? a[0] : out + a[0];
+    }
+    return out;
+}
+
+__global__ void __launch_bounds__(T) big_k_pcg_lean(BigDev d, int in, int out) {
+    __shared__ double red[2 * RED_MAXV * RED_MAXW];
+    int parity = 0;
+    const BigState *si = d.st + in;
+    if (si->halt || si->phase != 2) { forward_state(d, in, out); return; }
+    if (si->pcg_done) {
+        if (si->pcg_first)                                                       // rhs == 0: x := 0 (:273-278)
+            for (int q = 0; q < d.EPT; q++) { const int j = blockIdx.x * (T * d.EPT) + q * T + threadIdx.x; if (j < d.n_loc) d.xt[j] = 0.0; }
+        if (LEADER) { d.st[out] = *si; d.st[out].pcg_first = 0; }
+        return;
+    }
+    const int k = si->pcg_k;
+    const double dI = si->dI, r4Et = si->r4Et;
+    const double pp = lean_total(d, false, red, parity), qq = lean_total(d, true, red, parity);
+    const double pMp = dI * pp + r4Et * qq;
+    const double alpha = si->absNew / pMp;
+    const bool fail = alpha < 0;
+    const double *p = (k & 1) ? d.p1 : d.p0;
+    double pd2[2] = {0.0, 0.0};
+    if (!fail)
+        for (int q = 0; q < d.EPT; q++) {
+            const int j = blockIdx.x * (T * d.EPT) + q * T + threadIdx.x;
+            double a = 0.0, b2 = 0.0;
+            if (j < d.n_loc) {
+                const double pj = p[j];
+                double t = 0.0;
+                const int k1 = d.cptr[j + 1];
+                int kk = d.cptr[j];
+                for (; kk + 4 <= k1; kk += 4) {
+                    const int r0 = d.crow[kk], r1 = d.crow[kk + 1], r2 = d.crow[kk + 2], r3 = d.crow[kk + 3];
+                    const double v0 = d.q[r0], v1 = d.q[r1], v2 = d.q[r2], v3 = d.q[r3];
+                    t += r4Et * v0; t += r4Et * v1; t += r4Et * v2; t += r4Et * v3;
+                }
+                for (; kk < k1; kk++) t += r4Et * d.q[d.crow[kk]];
+                double Mp = 0.0;
+                Mp += dI * (1.0 * pj);
+                Mp += t;                                                         // tmp = M p (:298)
+                double x = d.xt[j], r = d.r[j];
+                x += alpha * pj;                                                 // :302
+                r -= alpha * Mp;                                                 // :304
+                const double z = d.dinv[j] * r;                                  // :314
+                const bool lv = d.live[j];
+                d.xt[j] = x; d.r[j] = r; d.z[j] = lv ? z : 0.0;
+                d.zp[j] = make_double2(lv ? z : 0.0, pj);
+                if (lv) { a = r * r; b2 = r * z; }
+            }
+            pd2[0] = pd2[0] + a; pd2[1] = pd2[1] + b2;
+        }
+    if (!fail) store_partials<2>(d, BIG_PH_D, pd2, red, parity);
+    if (LEADER) {
+        d.st[out] = *si;
+        if (fail) { d.st[out].pcg_done = 1; d.st[out].stop = LP_STOP_PCG; }
+        else d.st[out].pcg_k = k + 1;
+    }
+}
+
+// rank-ordered sum of this rank's block of E*v (as big_k_rank_sum) and, for the comm-lean PCG, the workgroup partials of q.q over the block:
+// one row per thread, 256 rows per workgroup
+__global__ void __launch_bounds__(T) big_k_rank_sum_qq(const double *g, int W, long count, long stride, double *out, double *qq_part) {
+    __shared__ double red[2 * RED_MAXV * RED_MAXW];
+    int parity = 0;
+    const long i = (long)blockIdx.x * T + threadIdx.x;
+    double c[1] = {0.0};
+    if (i < count) {
+        double acc = g[i];
+        for (int r = 1; r < W; r++) acc = acc + g[(long)r * stride + i];
+        out[i] = acc;
+        c[0] = c[0] + acc * acc;
+    }
+    block_sum<T, 1>(c, red, parity);
+    if (threadIdx.x == 0) qq_part[blockIdx.x] = c[0];
 }
 
 // after the PCG: duals z1, z2 (:917-918), the five partials (:931-1003), gsrc = x for the E*x that feeds z4 and the next y3
@@ -765,7 +892,17 @@ hipError_t big_launch_fin(const BigDev &d, int nv, int phase, hipStream_t s) {
 }
 hipError_t big_launch_y(const BigDev &d, int *parity, hipStream_t s) { BIG_LAUNCH(big_k_y, (d.G > d.Gl ? d.G : d.Gl)); return hipGetLastError(); }
 hipError_t big_launch_rhs_cols(const BigDev &d, int *parity, hipStream_t s) { BIG_LAUNCH(big_k_rhs_cols, d.G); return hipGetLastError(); }
-hipError_t big_launch_rows(const BigDev &d, int mode, int *parity, hipStream_t s) { BIG_LAUNCH(big_k_rows, (d.P > 1 ? d.Glr : d.Gl), mode); return hipGetLastError(); }
+hipError_t big_launch_rows(const BigDev &d, int mode, int *parity, hipStream_t s) {
+    const int rowgrid = d.P > 1 ? d.Glr : d.Gl;
+    BIG_LAUNCH(big_k_rows, (d.lean && mode == 1 && d.G > rowgrid ? d.G : rowgrid), mode);      // comm-lean: the column workgroups' p.p partials ride along
+    return hipGetLastError();
+}
+hipError_t big_launch_pcg_lean(const BigDev &d, int *parity, hipStream_t s) { BIG_LAUNCH(big_k_pcg_lean, d.G); return hipGetLastError(); }
+hipError_t big_launch_rank_sum_qq(const double *g, int W, long count, long stride, double *out, double *qq_part, hipStream_t s) {
+    if (count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(big_k_rank_sum_qq, dim3((unsigned)((count + T - 1) / T)), dim3(T), 0, s, g, W, count, stride, out, qq_part);
+    return hipGetLastError();
+}
 hipError_t big_launch_resid(const BigDev &d, int *parity, hipStream_t s) { BIG_LAUNCH(big_k_resid, d.G); return hipGetLastError(); }
 hipError_t big_launch_pcg_cols(const BigDev &d, int *parity, hipStream_t s) { BIG_LAUNCH(big_k_pcg_cols, d.G); return hipGetLastError(); }
 hipError_t big_launch_pcg_upd(const BigDev &d, int *parity, hipStream_t s) { BIG_LAUNCH(big_k_pcg_upd, d.G); return hipGetLastError(); }

@@ -84,6 +84,7 @@ SYMBOLS = {
     "lpbox_big_rccl_unique_id": (C.c_int, [C.c_void_p]),
     "lpbox_big_rccl_init": (C.c_int, [C.c_void_p, C.c_void_p]),
     "lpbox_big_set_problem": (C.c_int, [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, _ip, _ip, _dp, C.c_void_p]),
+    "lpbox_big_set_pcg_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "lpbox_big_init": (C.c_int, [C.c_void_p]),
     "lpbox_big_iterate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "lpbox_big_set_record": (C.c_int, [C.c_void_p, C.c_int]),

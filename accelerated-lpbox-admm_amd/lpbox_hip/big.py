@@ -32,7 +32,7 @@ def _dev_tensor(ptr, count):
 
 
 class BigLp:
-    def __init__(self, problem, rank=0, world=1, device=0, use_torch_stream=None, transport=None):
+    def __init__(self, problem, rank=0, world=1, device=0, use_torch_stream=None, transport=None, pcg_mode="reference"):
         """problem: dict(n, l, colptr, rowidx, b[, f]) of the WHOLE instance (CSC, 0/1 pattern, b already negated)."""
         self._L = _lib.load()
         self.rank, self.world = int(rank), int(world)
@@ -80,6 +80,10 @@ class BigLp:
             f = np.ascontiguousarray(f, np.float64)
             fp = f.ctypes.data_as(C.c_void_p)
         check(self._L.lpbox_big_set_problem(self._h, n, self.c0, self.c1 - self.c0, l, colptr, rowidx, b, fp), "lpbox_big_set_problem")
+        if pcg_mode not in ("reference", "lean"):
+            raise ValueError("pcg_mode must be 'reference' or 'lean'")
+        if pcg_mode == "lean":       # opt-in comm-lean PCG: not the reference's arithmetic (lpbox_big_set_pcg_mode in include/lpbox_hip.h)
+            check(self._L.lpbox_big_set_pcg_mode(self._h, 1), "lpbox_big_set_pcg_mode")
 
     def _allgather(self, send_ptr, count, recv_ptr, user):
         """recv[r*count:(r+1)*count] := rank r's send[0:count], ordered on the library's stream."""

@@ -613,15 +613,24 @@ def model_8_ranks(args, n, l, K, s_iter_1gpu, device):
     all l rows with 1/8 of their entries -- the l-sized kernels are under-counted, the launch-bound floor is not)."""
     from lpbox_hip.big import BigLp
     from lpbox_hip.synth import make_auction_like
-    P8 = make_auction_like(max(n // 8, 1000), 0)
-    g8 = BigLp(P8, device=device, use_torch_stream=True)
-    g8.solve_init(); g8.solve_iter(0, 100)                                  # warm (graphs, launch counts)
-    g8.solve_init()
     import torch
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    g8.solve_iter(0, 100)
-    torch.cuda.synchronize(); local_s = (time.perf_counter() - t0) / 100
-    g8.close()
+    P8 = make_auction_like(max(n // 8, 1000), 0)
+
+    def local(mode):
+        g8 = BigLp(P8, device=device, use_torch_stream=True, pcg_mode=mode)
+        g8.solve_init(); g8.solve_iter(0, 100)                              # warm (graphs, launch counts)
+        g8.solve_init()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        g8.solve_iter(0, 100)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 100
+        k = g8.scalar("pcg_total") / max(g8.scalar("outer_total"), 1)
+        g8.close()
+        return dt, k
+
+    local_s, _ = local("reference")
+    lean_s, lean_K = local("lean")
+    lean_ops = 7 + 3 * lean_K    # comm-lean PCG: K x (E*p with the p.p / q.q partials riding along 2, (r.r, r.z) 1)
+    lean_t = lean_s + lean_ops * RCCL_OP_LATENCY_US * 1e-6 + (lean_K + 2) * 2 * (l * 8 / 8) / (XGMI_LINK_GBS * 1e9)
     ops = 7 + 4 * K              # per outer iteration: prep 1, E*y1 2, resid 1, K x (E*p 2, p.Mp 1, (r.r, r.z) 1), post 1, E*x 2
     vec_exchanges = K + 2        # E*v exchanges: row blocks sent to their owner (all 7 links at once), reduced blocks gathered back
     bw_s = vec_exchanges * 2 * (l * 8 / 8) / (XGMI_LINK_GBS * 1e9)
@@ -630,6 +639,9 @@ def model_8_ranks(args, n, l, K, s_iter_1gpu, device):
     return {"ms_per_iteration": 1e3 * t, "iterations_per_s": 1.0 / t, "speedup_vs_1_gpu_measured_here": s_iter_1gpu / t,
             "local_work_ms": 1e3 * local_s, "rccl_operations_per_outer_iteration": ops, "latency_ms": 1e3 * lat_s, "bandwidth_ms": 1e3 * bw_s,
             "assumed_us_per_rccl_operation": RCCL_OP_LATENCY_US, "xgmi_link_GBps": XGMI_LINK_GBS,
+            "comm_lean_pcg": {"ms_per_iteration": 1e3 * lean_t, "speedup_vs_1_gpu_measured_here": s_iter_1gpu / lean_t,
+                              "local_work_ms": 1e3 * lean_s, "rccl_operations_per_outer_iteration": lean_ops,
+                              "note": "opt-in pcg_mode='lean' (NOT the reference's arithmetic): 3 instead of 4 dependent exchanges per PCG iteration"},
             "note": "MODEL, not a measurement: the three exchanges of a PCG iteration are sequentially dependent in the reference's "
                     "arithmetic, so their latency adds up; at the assumed latency 8 ranks buy little or nothing over one GPU "
                     "(DESIGN.md section 10)"}
@@ -658,6 +670,23 @@ def run_big(args, ctx, cpu_leg=None):
     sync()
     dt = time.perf_counter() - t0
     t_max = allred(dt, "MAX")
+    # the opt-in comm-lean PCG beside it (every rank: it has its own exchanges); reported under detail, never as `value`
+    gl = BigLp(P, rank=rank, world=world, device=local_rank, use_torch_stream=True, pcg_mode="lean")
+    gl.solve_init(); gl.solve_iter(0, window)
+    sync()
+    cl0, ll0 = gl.scalar("collectives"), gl.scalar("launches")
+    t0 = time.perf_counter()
+    lean_steps = max(1, min(args.steps, 5))
+    for _ in range(lean_steps):
+        gl.solve_init(); gl.solve_iter(0, window)
+    sync()
+    lean_t = allred(time.perf_counter() - t0, "MAX") / (lean_steps * window)
+    lean = {"ms_per_iteration": 1e3 * lean_t, "iterations_per_s": 1.0 / lean_t, "pcg_per_outer": gl.scalar("pcg_total") / max(gl.scalar("outer_total"), 1),
+            "launches_per_iteration": (gl.scalar("launches") - ll0) / (lean_steps * max(gl.scalar("outer_total"), 1)),
+            "exchanges_per_outer_iteration": (gl.scalar("collectives") - cl0) / (lean_steps * max(gl.scalar("outer_total"), 1)),
+            "note": "opt-in pcg_mode='lean': p.Mp = dI (p.p) + r4Et (q.q) -- not the reference's arithmetic, outside the parity claim "
+                    "(bit-exact against its own oracle mirror, tests/test_big_gpu_parity.py)"}
+    gl.close()
     line = None
     if rank == 0:
         o, p = g.scalar("outer_total"), g.scalar("pcg_total")        # of the last step
@@ -685,6 +714,7 @@ def run_big(args, ctx, cpu_leg=None):
                 "detail": {"pcg_per_outer": K, "ms_per_iteration": 1e3 * s_iter, "backend": backend if world > 1 else None}}
         line["detail"]["launches_per_iteration"] = launches_per_iter
         line["detail"]["folded_reductions"] = bool(g.scalar("folded_reductions"))
+        line["detail"]["comm_lean_pcg"] = lean
         if world == 1:
             line["detail"]["model_8_ranks"] = model_8_ranks(args, n, l, K, s_iter, local_rank)
         if world == 1 and (args.cpu_sample is None or args.cpu_sample > 0):

@@ -232,6 +232,13 @@ int lpbox_big_rccl_unique_id(void *out128);                    /* ncclGetUniqueI
 int lpbox_big_rccl_init(lpbox_big_t *h, const void *unique_id128);   /* ncclCommInitRank(world, id, rank) on the handle's device */
 int lpbox_big_set_problem(lpbox_big_t *h, long n_glob, int c0, int n_loc, int l, const int *colptr, const int *rowidx,
                           const double *b, const double *f);
+/* Opt-in, NOT the reference's arithmetic and outside the parity claim (like lpbox_set_x_update): the PCG's step length from
+ * p.Mp = dI (p.p) + r4Et (q.q), q = E p, instead of the dot product p.(M p) of LPcpp:300 -- the p.p partials ride with the q exchange, the column
+ * product and the vector updates become one kernel: 3 instead of 4 RCCL operations and 2 instead of 3 launches per PCG iteration.  Call before
+ * lpbox_big_init.  Bit-exact against its own oracle mirror (lpo_set_pcg_lean). */
+#define LPBOX_PCG_REFERENCE 0
+#define LPBOX_PCG_COMM_LEAN 1
+int lpbox_big_set_pcg_mode(lpbox_big_t *h, int mode);
 int lpbox_big_init(lpbox_big_t *h);                                             /* ADMM_lp_iters_init LPcpp:489-763 */
 int lpbox_big_iterate(lpbox_big_t *h, int iter_start, int iter_end, int *ret);  /* ADMM_lp_iters      LPcpp:766-1095 */
 /* print_fix_info 2 behind the size hand-over (LPcpp:777-780, :903-909): the following lpbox_big_iterate calls keep x after every

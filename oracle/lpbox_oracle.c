@@ -177,6 +177,9 @@ struct lpo {
     int *gpu_pos; int gpu_pos_n;   /* storage position of each original variable in the kernels (NULL = identity) */
     int gpu_npos;                  /* number of storage positions (>= org_n; holes contribute +0.0) */
     int gpu_chunk;                 /* > 0: two-level order of the large-instance kernels (workgroup partials of `chunk` positions) */
+    int pcg_lean, lean_row_chunk;  /* the large-instance kernels' opt-in comm-lean PCG (NOT the reference's arithmetic): p.Mp = dI (p.p) + r4Et (q.q),
+                                      q = E p; q.q summed over the rows in workgroup chunks of lean_row_chunk rows (lpo_set_pcg_lean) */
+    double *lean_buf;
     int gpu_ranks;                 /* > 1: the variable-sharded run (lpbox_big_*): contiguous blocks of variables per rank, every sum over
                                       variables = per-rank sums (each in the order above, positions counted from the rank's first variable)
                                       added in rank order p0 + p1 + p2 ... */
@@ -283,7 +286,7 @@ lpo_t *lpo_create(int print_info) {
 
 static void free_state(lpo_t *o) {
     free(o->x); free(o->y1); free(o->y2); free(o->z1); free(o->z2); free(o->y3); free(o->z4);
-    free(o->temp_vec); free(o->temp_cg); free(o->temp_mm); free(o->Dd); free(o->pd); free(o->Esq);
+    free(o->temp_vec); free(o->temp_cg); free(o->temp_mm); free(o->Dd); free(o->pd); free(o->Esq); free(o->lean_buf); o->lean_buf = NULL;
     free(o->invdiag); free(o->obj_list); free(o->best_sol); free(o->x_iters); free(o->left_idx);
     free(o->ret_idx_prev); free(o->ret_val_prev); free(o->ret_idx); free(o->ret_val);
     free(o->pcg_trace); free(o->full); free(o->fy); free(o->x_try); free(o->full_v);
@@ -315,6 +318,10 @@ void lpo_set_order(lpo_t *o, int mode, int T) {
 void lpo_set_verbose(lpo_t *o, int verbose) { o->verbose = verbose; }
 void lpo_set_chunk(lpo_t *o, int chunk) { o->gpu_chunk = chunk > 0 ? chunk : 0; }
 void lpo_set_ranks(lpo_t *o, int ranks) { o->gpu_ranks = ranks > 1 ? ranks : 0; }
+/* Mirror of lpbox_big_set_pcg_mode(LPBOX_PCG_COMM_LEAN) -- no reference counterpart: the step length of the PCG is taken from
+ * p.Mp = dI (p.p) + r4Et (q.q) with q = E p instead of the dot product p.(M p) (LPcpp:300), everything else unchanged.  row_chunk = rows per
+ * workgroup of the kernel that squares q (one rank: the row-gather kernel's; several ranks: 256, one row per thread of the block sum). */
+void lpo_set_pcg_lean(lpo_t *o, int on, int row_chunk) { o->pcg_lean = on != 0; o->lean_row_chunk = row_chunk > 0 ? row_chunk : 256; }
 void lpo_set_x_update(lpo_t *o, int mode) { o->x_update = mode == 1 ? 1 : 0; o->H_valid = 0; }
 void lpo_set_direct_rows(lpo_t *o, const int *gidx_of_row, int l) {
     free(o->dir_g);
@@ -557,6 +564,27 @@ static void mat_expr_mul(lpo_t *o, const double *x, double *result) {
     for (int j = 0; j < n; j++) result[j] += t2[j];
 }
 
+/* q.q over the rows in the order of the large-instance kernels' comm-lean PCG: per rank block (one rank: all rows) the two-level tree --
+ * workgroup chunks, then the chunk partials -- and the block totals added in rank order (blocks of ceil(l / W) rows, as the q exchange) */
+static double rows_sqsum_gpu(lpo_t *o, const double *q) {
+    const int l = o->l, T = o->T, W = o->gpu_ranks > 1 ? o->gpu_ranks : 1;
+    if (!o->lean_buf) o->lean_buf = (double *)malloc(sizeof(double) * ((size_t)l + (size_t)l / 64 + 1024));
+    double *sq = o->lean_buf, *part = o->lean_buf + l;
+    for (int i = 0; i < l; i++) sq[i] = q[i] * q[i];
+    const int lb = (l + W - 1) / W, CH = W > 1 ? T : o->lean_row_chunk;
+    double total = 0.0;
+    for (int rk = 0; rk < W; rk++) {
+        const int lo = rk * lb < l ? rk * lb : l, hi = lo + lb < l ? lo + lb : l, nloc = hi - lo, Gn = (nloc + CH - 1) / CH;
+        for (int g = 0; g < Gn; g++) {
+            int len = nloc - g * CH; if (len > CH) len = CH;
+            part[g] = redux_sum_gpu_full(sq + lo + (size_t)g * CH, len, T);
+        }
+        const double pr = redux_sum_gpu_full(part, Gn, T);
+        total = rk == 0 ? pr : total + pr;
+    }
+    return total;
+}
+
 /* _conjugate_gradient, the int-returning overload LPcpp:251-335 (verbatim Eigen CG + Jacobi) */
 static int conjugate_gradient(lpo_t *o, const double *rhs, double *x, int *iters_io, double *tol_io) {
     const int n = o->n;
@@ -586,7 +614,13 @@ static int conjugate_gradient(lpo_t *o, const double *rhs, double *x, int *iters
     int i = 0;
     while (i < maxIters) {                                        /* :296 */
         mat_expr_mul(o, p, tmp);                                  /* :298 */
-        double alpha = absNew / dot_live(o, p, tmp);              /* :300 */
+        double pMp;
+        if (o->pcg_lean) {                                        /* opt-in, not the reference's: see lpo_set_pcg_lean */
+            const double pp = dot_live(o, p, p), qq = rows_sqsum_gpu(o, o->temp_mm);   /* temp_mm[0..l) = E p, left there by mat_expr_mul */
+            const double r4 = o->r4Et.nnz > 0 ? o->r4Et.val[0] / o->Et.val[0] : o->rho4;   /* the scalar the kernels carry (entries of E are 1) */
+            pMp = o->Dd[0] * pp + r4 * qq;
+        } else pMp = dot_live(o, p, tmp);
+        double alpha = absNew / pMp;                              /* :300 */
         if (alpha < 0) { *iters_io = i; return -1; }              /* :301 */
         for (int k = 0; k < n; k++) x[k] += alpha * p[k];         /* :302 */
         for (int k = 0; k < n; k++) residual[k] -= alpha * tmp[k];/* :304 */

@@ -52,6 +52,8 @@ void lpo_set_col_split(lpo_t *o, const int *own, const int *help4, int n);
 void lpo_set_chunk(lpo_t *o, int chunk);
 /* GPU order of the variable-sharded run: `ranks` contiguous blocks of variables; per-rank sums added in rank order (needs lpo_set_chunk) */
 void lpo_set_ranks(lpo_t *o, int ranks);
+/* mirror of the large-instance kernels' opt-in comm-lean PCG (no reference counterpart): p.Mp = dI (p.p) + r4Et (q.q), q = E p */
+void lpo_set_pcg_lean(lpo_t *o, int on, int row_chunk);
 /* 0 = the reference's Jacobi-PCG x-update (default); 1 = the HIP kernels' opt-in DIRECT x-update (Woodbury with a dense l x l inverse;
  * NOT the reference's algorithm -- mirrored here only so that the kernel mode has a bit-exact checker) */
 void lpo_set_x_update(lpo_t *o, int mode);

@@ -44,6 +44,7 @@ def lib():
     L.lpo_set_verbose.argtypes = [C.c_void_p, C.c_int]
     L.lpo_set_chunk.argtypes = [C.c_void_p, C.c_int]
     L.lpo_set_ranks.argtypes = [C.c_void_p, C.c_int]
+    L.lpo_set_pcg_lean.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.lpo_set_x_update.argtypes = [C.c_void_p, C.c_int]
     L.lpo_set_direct_rows.argtypes = [C.c_void_p, _ip, C.c_int]
     L.lpo_set_log.argtypes = [C.c_void_p, C.c_char_p]
@@ -108,6 +109,10 @@ class LpOracle:
             own = np.ascontiguousarray(col_split[0], np.int32)
             help4 = np.ascontiguousarray(col_split[1], np.int32).ravel()
             self.L.lpo_set_col_split(self.h, own, help4, len(own))
+
+    def set_pcg_lean(self, on=True, row_chunk=256):
+        """Mirror of BigLp.set_pcg_mode("lean"): the kernels' opt-in comm-lean PCG (no reference counterpart)."""
+        self.L.lpo_set_pcg_lean(self.h, 1 if on else 0, int(row_chunk))
 
     def set_x_update(self, mode, direct_rows=None):
         """Switch between the reference's PCG and the kernels' opt-in direct x-update between calls (lpbox_set_x_update)."""
