@@ -231,3 +231,33 @@ def test_oracle_pool_worker_under_spawn():
     for job, r in zip(jobs, res):
         here = oracle_full_solve(job)
         assert r[:4] == here[:4] and np.array_equal(r[4], here[4]) and np.array_equal(r[5], here[5])
+
+
+def test_pcg_lean_mirror_is_the_same_algebra_with_another_rounding():
+    """lpo_set_pcg_lean (mirror of the large-instance kernels' opt-in comm-lean PCG): p.Mp = dI (p.p) + r4Et (q.q) is the reference's
+    p.(M p) in exact arithmetic -- the first iterates agree to rounding and the PCG counts are the same; further on it is a different
+    trajectory of the same heuristic (different bits), and the grouping of the q.q partials matters to the last bit only."""
+    I = lp_instances("lp_100_500_seed0.npz")[0]
+    ref = make_oracle(I, O.ORDER_GPU, 256)
+    lean = O.LpOracle(0, order=O.ORDER_GPU, T=256)
+    lean.set_pcg_lean(True, 512)
+    lean.set_problem(I["n"], I["l"], I["colptr"], I["rowidx"], I["b"])
+    lean.solve_init()
+    other = O.LpOracle(0, order=O.ORDER_GPU, T=256)
+    other.set_pcg_lean(True, 64)
+    other.set_problem(I["n"], I["l"], I["colptr"], I["rowidx"], I["b"])
+    other.solve_init()
+    for o in (ref, lean, other):
+        o.solve_iter(0, 1)
+    d1 = np.abs(ref.vec("x") - lean.vec("x")).max()
+    assert 0 < d1 < 1e-7, d1                                  # rounding of alpha only
+    for o in (ref, lean, other):
+        o.solve_iter(1, 6)
+    assert np.array_equal(ref.pcg_trace(), lean.pcg_trace())
+    assert np.abs(ref.vec("x") - lean.vec("x")).max() < 5e-4  # ... amplified like any other rounding difference (cf. the summation-order test above)
+    assert np.abs(other.vec("x") - lean.vec("x")).max() < 5e-4
+    for o in (ref, lean):
+        o.solve_iter(6, 20000)
+    for o in (ref, lean):
+        x = o.vec("x")
+        assert np.all((x == 0) | (x == 1))
