@@ -39,6 +39,12 @@
 #else
 #define POL_FF_CHUNKS 4
 #endif
+// finer knock-outs (timing only; tools/policy_body.py): POL_NO_QKV (no Q|K|V GEMM, no epilogue), POL_NO_QKV_EPI / POL_NO_FF_EPI (GEMM kept, LDS
+// stores behind a condition that is false at run time), POL_NO_PROJ, POL_NO_OUT (no global store of the result), POL_NO_IN (no global read
+// of x), POL_W_ONCE (no weight traffic: zero fragments)
+#if defined(POL_NO_QKV_EPI) || defined(POL_NO_FF_EPI)
+#define POL_EPI_GUARD(pa) ((pa).rows < 0)
+#endif
 
 namespace {
 
@@ -50,11 +56,28 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int PM = POLICY_TOKENS_PER_WG;   // 160
 constexpr int E = 128;
-constexpr int LDA = 136;               // halves per row of a 128-wide LDS image
+#ifndef POL_SWIZZLE
+constexpr int LDA = 136;               // halves per row of a 128-wide LDS image: rows padded by 16 bytes
+#else
+constexpr int LDA = 128;               // A/B build: no padding, 16-byte slots XOR-swizzled by the row (swz)
+#endif
 constexpr int LDQ = 72;                // halves per row of a 64-wide LDS image (Q, K, V of four heads)
 constexpr int QROWS = 176;             // 160 + 16 pad rows: the 32-row MFMA operands of the last variable stay in bounds
 constexpr int LDV = 184;               // halves per row of the transposed V image [feature][token]: 160 tokens + 24 zeroed pad columns
 constexpr int MT = 5;                  // 16-row tiles per wave (2 x 4 wave grid over 10 x N/16 tiles)
+
+// Address (in halves) of column col of row `row` in a 128-wide image.  -DPOL_SWIZZLE (A/B build): unpadded rows, the 16-byte slot s of row r at
+// slot s ^ (r & 15).  ds_read_b128 serves a wave in four groups of 16 lanes ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...; banks =
+// 16-byte slots of a 256-byte row); a fragment read has lane (r = lane & 15, g = lane >> 4) on slot g + 4 ks of row r, and the padded
+// rows put two lanes of every group on one slot (8 LDS cycles per read instead of 4).  The swizzle removes that -- measured:
+// SQ_LDS_BANK_CONFLICT 333 M -> 105 M, conflict share 0.46 -> 0.21, LDS-active cycles -32 % -- and the kernel is 2.5 % SLOWER (2.86 vs
+// 2.79 ms): the LDS is active 30-45 % of the time either way, the waves wait on the latency of their own fragment reads, and the
+// swizzled addresses cost the paired stores (ds_write2_b64) and extra waits.  Default: padded.  
+#ifndef POL_SWIZZLE
+__device__ __forceinline__ int swz(int row, int col) { return row * LDA + col; }
+#else
+__device__ __forceinline__ int swz(int row, int col) { return row * LDA + (col ^ ((row & 15) << 3)); }
+#endif
 
 struct Lds {
     f16 h[PM * LDA];          // fp16 image of the residual stream (A operand of the QKV and FF-up GEMMs)
@@ -76,6 +99,15 @@ struct WFrag { f16x8 v[4][NT]; };
 // fragment (feature tile, k-step) at (tile*4 + ks)*64 + lane.  Issued well before use: the loads fly while the previous GEMM runs.
 template <int NT>
 __device__ __forceinline__ void load_w(WFrag<NT> &w, const f16x8 *wp, int tile0, int tstride, int lane) {
+#ifdef POL_W_ONCE      // timing only: no weight traffic at all (what do the GEMMs wait for?)
+    if (lane >= 0) {
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) w.v[ks][nt] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        return;
+    }
+#endif
 #pragma unroll
     for (int nt = 0; nt < NT; nt++)
 #pragma unroll
@@ -84,6 +116,15 @@ __device__ __forceinline__ void load_w(WFrag<NT> &w, const f16x8 *wp, int tile0,
 // the wave's tiles of one Q|K|V block of four heads (12 feature tiles: Q of heads 0-3, K, V): PER of each third, starting at head PER * wn
 template <int PER>
 __device__ __forceinline__ void load_w_qkv(WFrag<3 * PER> &w, const f16x8 *wp, int wn, int lane) {
+#ifdef POL_W_ONCE
+    if (lane >= 0) {
+#pragma unroll
+        for (int nt = 0; nt < 3 * PER; nt++)
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) w.v[ks][nt] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        return;
+    }
+#endif
 #pragma unroll
     for (int nt = 0; nt < 3 * PER; nt++)
 #pragma unroll
@@ -98,18 +139,24 @@ __device__ __forceinline__ void load_w_qkv(WFrag<3 * PER> &w, const f16x8 *wp, i
 // TOKENS of one feature, which is what the transposed V image wants.
 template <int NT, int PLAIN = 0>
 __device__ __forceinline__ void gemm_tiles(const f16 *act, int lda, int row0, const WFrag<NT> &w, f32x4 (&acc)[MT][NT], int lane) {
-    const f16 *arow = act + (size_t)(row0 + (lane & 15)) * lda + 8 * (lane >> 4);
+    // row0 is a multiple of 16, so row & 15 = lane & 15 for every tile: the (swizzled) column of k-step ks is cb ^ (32 ks) (= cb + 32 ks unswizzled)
+    const f16 *arow = act + (size_t)(row0 + (lane & 15)) * lda;
+#ifndef POL_SWIZZLE
+    const int cb = 8 * (lane >> 4);
+#else
+    const int cb = (8 * (lane >> 4)) ^ ((lane & 15) << 3);
+#endif
     if constexpr (NT >= 4) {
         // one wave per SIMD (the 2 x 2 wave grid): nobody else hides the LDS latency, so the activation fragments of k-step ks + 1 are
         // requested before the MFMAs of k-step ks are issued (two register sets of MT fragments)
         f16x8 a[2][MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++) a[0][mt] = *(const f16x8 *)(arow + (size_t)mt * 16 * lda);
+        for (int mt = 0; mt < MT; mt++) a[0][mt] = *(const f16x8 *)(arow + (size_t)mt * 16 * lda + cb);
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) {
             if (ks < 3) {
 #pragma unroll
-                for (int mt = 0; mt < MT; mt++) a[(ks + 1) & 1][mt] = *(const f16x8 *)(arow + (size_t)mt * 16 * lda + (ks + 1) * 32);
+                for (int mt = 0; mt < MT; mt++) a[(ks + 1) & 1][mt] = *(const f16x8 *)(arow + (size_t)mt * 16 * lda + (cb ^ ((ks + 1) * 32)));
             }
 #pragma unroll
             for (int mt = 0; mt < MT; mt++)
@@ -123,7 +170,7 @@ __device__ __forceinline__ void gemm_tiles(const f16 *act, int lda, int row0, co
     for (int ks = 0; ks < 4; ks++) {
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {
-            const f16x8 a = *(const f16x8 *)(arow + (size_t)mt * 16 * lda + ks * 32);
+            const f16x8 a = *(const f16x8 *)(arow + (size_t)mt * 16 * lda + (cb ^ (ks * 32)));
 #pragma unroll
             for (int nt = 0; nt < NT; nt++)
                 acc[mt][nt] = (nt >= NT - PLAIN) ? mfma16(a, w.v[ks][nt], acc[mt][nt]) : mfma16(w.v[ks][nt], a, acc[mt][nt]);
@@ -181,7 +228,9 @@ __global__ void __launch_bounds__(128 * NW) policy_body_kernel(PolicyArgs pa) {
         const int tok = e / 5, c = e - tok * 5;
         const int v = tok / TOK, t = tok - v * TOK;
         float val = 0.f;
+#ifndef POL_NO_IN
         if (v < nvar) val = (float)pa.x[pa.row_off[var0 + v] + (long)t * pa.tok_stride + c];
+#endif
         xs[e] = val;
     }
     // pad columns of V^T (keys beyond the last variable's tokens) meet probabilities that are exactly 0: they must be finite.
@@ -216,7 +265,7 @@ __global__ void __launch_bounds__(128 * NW) policy_body_kernel(PolicyArgs pa) {
     for (int mt = 0; mt < MT; mt++)
 #pragma unroll
         for (int nt = 0; nt < NTO; nt++)
-            store4(S.h + (row0 + mt * 16 + l15) * LDA + (wn * NTO + nt) * 16 + g4, H[mt][nt][0], H[mt][nt][1], H[mt][nt][2], H[mt][nt][3]);
+            store4(S.h + swz(row0 + mt * 16 + l15, (wn * NTO + nt) * 16 + g4), H[mt][nt][0], H[mt][nt][1], H[mt][nt][2], H[mt][nt][3]);
     __syncthreads();
 
 #pragma unroll
@@ -230,8 +279,16 @@ __global__ void __launch_bounds__(128 * NW) policy_body_kernel(PolicyArgs pa) {
             {   // Q | K | V of heads 4 half .. 4 half + 3:  (160 x 128) x (128 x 192); meanwhile fetch the next GEMM's weights
                 f32x4 acc[MT][NTQ];
                 zero_acc<NTQ>(acc);
+#ifdef POL_NO_QKV
+                if (half == 0) load_w_qkv<PER>(w3b, wl + (size_t)48 * 64, wn, lane); else load_w<NTO>(w2a, wl + (size_t)96 * 64, wn * NTO, 1, lane);
+                if (pa.rows < 0)
+#else
                 if (half == 0) { load_w_qkv<PER>(w3b, wl + (size_t)48 * 64, wn, lane); gemm_tiles<NTQ, PER>(S.h, LDA, row0, w3a, acc, lane); }
                 else           { load_w<NTO>(w2a, wl + (size_t)96 * 64, wn * NTO, 1, lane); gemm_tiles<NTQ, PER>(S.h, LDA, row0, w3b, acc, lane); }
+#endif
+#ifdef POL_NO_QKV_EPI
+                if (POL_EPI_GUARD(pa))
+#endif
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++) {
                     const int tok = row0 + mt * 16 + l15;
@@ -294,13 +351,13 @@ __global__ void __launch_bounds__(128 * NW) policy_body_kernel(PolicyArgs pa) {
                     for (int i = 0; i < 16; i++) {
                         const int kmin = (i & 3) + 8 * (i >> 2);
                         if (kmin >= TOK) { st[i] = 0.f; continue; }
-                        float p = exp2f(fmaf(st[i], 1.44269504088896f, -mxl));
+                        float p = __builtin_amdgcn_exp2f(fmaf(st[i], 1.44269504088896f, -mxl));   // raw v_exp_f32 (exp2f() wraps it in five more instructions for denormal results): the argument is <= 0, a result below 2^-126 may flush to 0
                         if (kmin + 4 >= TOK) p = hf == 0 ? p : 0.f;
                         st[i] = p;
                         sum += p;
                     }
                     sum += swap_halves(sum);
-                    const float inv = 1.f / sum;
+                    const float inv = __builtin_amdgcn_rcpf(sum);                  // sum >= 1 (the maximum contributes exp2(0)); 1 ulp instead of the IEEE division's sequence
                     f32x16 o;
 #pragma unroll
                     for (int i = 0; i < 16; i++) o[i] = 0.f;
@@ -314,9 +371,9 @@ __global__ void __launch_bounds__(128 * NW) policy_body_kernel(PolicyArgs pa) {
                         }
                     }
                     if (r31 < TOK) {
-                        f16 *dst = S.ao + (tok0 + r31) * LDA + (half * 4 + hh) * 16 + 4 * hf;
-                        store4(dst, o[0], o[1], o[2], o[3]);
-                        store4(dst + 8, o[4], o[5], o[6], o[7]);
+                        const int oc = (half * 4 + hh) * 16 + 4 * hf;
+                        store4(S.ao + swz(tok0 + r31, oc), o[0], o[1], o[2], o[3]);
+                        store4(S.ao + swz(tok0 + r31, oc + 8), o[4], o[5], o[6], o[7]);
                     }
                 }
             }
@@ -328,7 +385,9 @@ __global__ void __launch_bounds__(128 * NW) policy_body_kernel(PolicyArgs pa) {
             f32x4 acc[MT][NTO];
             zero_acc<NTO>(acc);
             load_w<NTO>(w2b, wl + (size_t)128 * 64, wn * NTO, 1, lane);          // FF-up chunk 0
+#ifndef POL_NO_PROJ
             gemm_tiles<NTO>(S.ao, LDA, row0, w2a, acc, lane);
+#endif
 #pragma unroll
             for (int nt = 0; nt < NTO; nt++) {
                 const int f0 = (wn * NTO + nt) * 16 + g4;
@@ -337,7 +396,7 @@ __global__ void __launch_bounds__(128 * NW) policy_body_kernel(PolicyArgs pa) {
                 for (int mt = 0; mt < MT; mt++) {
                     const f32x4 hv = (H[mt][nt] + acc[mt][nt]) * s1 + t1;
                     H[mt][nt] = hv;
-                    store4(S.h + (row0 + mt * 16 + l15) * LDA + f0, hv[0], hv[1], hv[2], hv[3]);
+                    store4(S.h + swz(row0 + mt * 16 + l15, f0), hv[0], hv[1], hv[2], hv[3]);
                 }
             }
         }
@@ -354,6 +413,9 @@ __global__ void __launch_bounds__(128 * NW) policy_body_kernel(PolicyArgs pa) {
                     zero_acc<NTO>(acc);
                     load_w<NTO>(w2a, wl + (size_t)(256 + c * 32) * 64, wn * NTO, 1, lane);  // FF-down chunk c
                     gemm_tiles<NTO>(S.h, LDA, row0, w2b, acc, lane);
+#ifdef POL_NO_FF_EPI
+                    if (POL_EPI_GUARD(pa))
+#endif
 #pragma unroll
                     for (int nt = 0; nt < NTO; nt++) {
                         const int f0 = (wn * NTO + nt) * 16 + g4;
@@ -361,7 +423,7 @@ __global__ void __launch_bounds__(128 * NW) policy_body_kernel(PolicyArgs pa) {
 #pragma unroll
                         for (int mt = 0; mt < MT; mt++) {
                             const f32x4 hv = acc[mt][nt] + b1;
-                            store4(S.u.ff + (row0 + mt * 16 + l15) * LDA + f0, fmaxf(hv[0], 0.f), fmaxf(hv[1], 0.f), fmaxf(hv[2], 0.f), fmaxf(hv[3], 0.f));
+                            store4(S.u.ff + swz(row0 + mt * 16 + l15, f0), fmaxf(hv[0], 0.f), fmaxf(hv[1], 0.f), fmaxf(hv[2], 0.f), fmaxf(hv[3], 0.f));
                         }
                     }
                 }
@@ -380,7 +442,7 @@ __global__ void __launch_bounds__(128 * NW) policy_body_kernel(PolicyArgs pa) {
                 for (int mt = 0; mt < MT; mt++) {
                     const f32x4 hv = (H[mt][nt] + acc2[mt][nt] + b2) * s2 + t2;
                     H[mt][nt] = hv;
-                    store4(S.h + (row0 + mt * 16 + l15) * LDA + f0, hv[0], hv[1], hv[2], hv[3]);
+                    store4(S.h + swz(row0 + mt * 16 + l15, f0), hv[0], hv[1], hv[2], hv[3]);
                 }
             }
         }
@@ -393,7 +455,12 @@ __global__ void __launch_bounds__(128 * NW) policy_body_kernel(PolicyArgs pa) {
         const int ntok = nvar * TOK;
         for (int e = tid; e < PM * (E / 8); e += PT) {
             const int tok = e >> 4, c8 = e & 15;
-            if (tok < ntok) *(f16x8 *)(out + (long)tok * E + c8 * 8) = *(const f16x8 *)(S.h + tok * LDA + c8 * 8);
+#ifdef POL_NO_OUT
+            if (tok < ntok && pa.rows < 0)
+#else
+            if (tok < ntok)
+#endif
+                *(f16x8 *)(out + (long)tok * E + c8 * 8) = *(const f16x8 *)(S.h + swz(tok, c8 * 8));
         }
     }
 }
