@@ -9,8 +9,11 @@
 Configs 2 / 4: a "step" = one complete solve of the batch (ADMM_lp_iters_init + ADMM_lp_iters(0, 2e4) for every instance, each
 stopping on its own reference stop test, LPcpp:934/:977) = one launch of the persistent window kernel; `value` = instance-iterations
 executed by all ranks / time; ms_per_step = wall-clock to converge.  With --gpus N every rank holds its own 256-instance shard
-(instance-sharded, no data-path collective, weak scaling): rank 0 the fixture, rank r > 0 the same LPs with bids and items
-relabelled by a rank-seeded permutation (isomorphic problems, different arithmetic trajectories and iteration counts).
+(instance-sharded, no data-path collective, weak scaling): rank 0 the fixture = instances 0..255 of the reference generator's seed-0
+stream, rank r > 0 instances 256 r .. 256 r + 255 of the SAME stream (BASELINE configs[3]: 2048 draws over 8 GPUs), produced on the spot by
+the draw-for-draw restatement of the generator in lpbox_hip/auction.py from the generator states stored in tests/golden/lp_stream_*.npz
+and checked against the digests stored there.  (LPBOX_BENCH_SHARD=relabel, or a missing stream fixture: the round-2 behaviour -- rank 0's
+LPs with bids and items relabelled by a rank-seeded permutation.)
 Config 3: step = one ADMM_bqp_unconstrained_legacy solve; config 5: step = init + 100 ADMM iterations of the sharded instance.
 
 Launch:  python bench.py [--config C] [--gpus N] [--steps K] [--warmup W]
@@ -378,12 +381,26 @@ def finish(world):
 # ------------------------------------------------------------------------------------------------------------------------
 # configs 2 and 4: batches of independent LP instances on the persistent one-workgroup-per-instance kernel
 # ------------------------------------------------------------------------------------------------------------------------
+SHARD_SOURCE = {}       # rank -> how its shard was made (for the `data` field)
+
+
 def lp_shard(args, rank):
     c4 = args.config == 4
     insts = load_instances(FIXTURE_C4 if c4 else FIXTURE)
     shard = [insts[i % len(insts)] for i in range(args.batch)]
+    SHARD_SOURCE[rank] = "fixture"
     if rank > 0:
-        shard = [relabel(I, 1000 * rank + i) for i, I in enumerate(shard)]
+        items, bids = (500, 2000) if c4 else (100, 500)
+        from lpbox_hip import auction
+        fx = auction.default_stream_fixture(items, bids)
+        first = len(insts) * rank
+        if (not STUB and os.environ.get("LPBOX_BENCH_SHARD", "stream") != "relabel" and args.batch == len(insts) and os.path.exists(fx)
+                and first + args.batch <= len(np.load(fx)["n"])):
+            shard = auction.stream_instances(items, bids, first, args.batch, fixture=fx, workers=max(1, min(16, usable_cpus() // max(1, args.gpus))))
+            SHARD_SOURCE[rank] = "stream"
+        else:
+            shard = [relabel(I, 1000 * rank + i) for i, I in enumerate(shard)]
+            SHARD_SOURCE[rank] = "relabel"
     return shard, len(insts)
 
 
@@ -403,6 +420,7 @@ def run_lp_batch(args, ctx, cpu_leg=None):
     rank, world, local_rank, sync, allred = ctx.rank, ctx.world, ctx.local_rank, ctx.sync, ctx.allred
     c4 = args.config == 4
     shard, n_distinct = lp_shard(args, rank)
+    shard_source = "stream" if world > 1 and allred(1.0 if SHARD_SOURCE.get(rank) in ("stream", "fixture") else 0.0, "MIN") > 0 else "relabel"
     cpu, cpu_obj, cpu_it = cpu_leg if cpu_leg is not None else (None, None, None)
     if STUB:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -486,8 +504,11 @@ def run_lp_batch(args, ctx, cpu_leg=None):
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": f"synthetic (reference generator, RandomState(0), first {min(B, n_distinct)} draws {size}; rank r > 0: the same LPs "
-                    "relabelled by a rank-seeded permutation)" + (" -- STUB SOLVER, launch-path test only, not a measurement" if STUB else ""),
+            "data": f"synthetic (reference generator, RandomState(0), draws 0..{min(B, n_distinct) - 1} {size} on rank 0"
+                    + ("" if world == 1 else (f"; rank r: draws {B} r .. {B} r + {B - 1} of the same stream, regenerated draw for draw by lpbox_hip/auction.py "
+                                              "and checked against the reference generator's digests" if shard_source == "stream" else
+                                              "; rank r > 0: the same LPs relabelled by a rank-seeded permutation"))
+                    + ")" + (" -- STUB SOLVER, launch-path test only, not a measurement" if STUB else ""),
             "config": {"workload": f"batch of {B} {size} combinatorial-auction LP instances per GPU, fp64, full solve "
                                    "(init + ADMM_lp_iters(0,2e4)) = 1 step (BASELINE configs[%d])" % (3 if c4 else 1),
                        "instances_per_gpu": B, "threads_per_instance": cfg["threads"], "slots_per_thread": cfg["elems_per_thread"],
