@@ -100,7 +100,7 @@ def auction_instance(rng, n_items=100, n_bids=500, add_item_prob=0.7):
     colptr[1:] = np.cumsum([len(r) for r, _ in bids])
     rowidx = np.fromiter((i for r, _ in bids for i in r), np.int32, count=int(colptr[-1]))
     price = np.array([p for _, p in bids], np.float64)
-    return dict(n=n, l=int(rowidx.max()) + 1, colptr=colptr, rowidx=rowidx, b=-1.0 * price)
+    return dict(n=n, l=int(rowidx.max()) + 1, nnz=int(colptr[-1]), colptr=colptr, rowidx=rowidx, b=-1.0 * price)
 
 
 def digest(inst):
