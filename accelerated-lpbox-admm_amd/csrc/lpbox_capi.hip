@@ -1002,6 +1002,26 @@ int lpbox_policy_encode_f16(const double *x_dev, const long long *row_off_dev, l
     return LPBOX_OK;
 }
 
+int lpbox_policy_f32frag_layout(int tokens, long *weight_floats, long *const_floats) {
+    if (tokens != 20 && tokens != 5) return fail(LPBOX_E_BADARG, "tokens must be 20 (LP) or 5 (segmentation)");
+    if (weight_floats) *weight_floats = policy_f32frag_floats();
+    if (const_floats) *const_floats = POLICY_OFF_LAYER(tokens) + 2L * POLICY_LAYER_CONSTS;
+    return LPBOX_OK;
+}
+
+int lpbox_policy_encode_f32(const double *x_dev, const long long *row_off_dev, long rows, int tokens, int tok_stride,
+                            const float *weights_dev, const float *consts_dev, float *out_dev, void *hip_stream) {
+    if (tokens != 20 && tokens != 5) return fail(LPBOX_E_BADARG, "tokens must be 20 (LP) or 5 (segmentation)");
+    if (rows < 0 || tok_stride < 1) return fail(LPBOX_E_BADARG, "bad rows / token stride");
+    if (rows == 0) return LPBOX_OK;
+    if (!x_dev || !row_off_dev || !weights_dev || !consts_dev || !out_dev) return fail(LPBOX_E_BADARG, "null device pointer");
+    PolicyArgs pa;
+    pa.x = x_dev; pa.row_off = row_off_dev; pa.rows = rows; pa.tok_stride = tok_stride;
+    pa.weights = weights_dev; pa.consts = consts_dev; pa.out = out_dev;
+    HIPCHK(policy_launch_body_f32(pa, tokens, (hipStream_t)hip_stream));
+    return LPBOX_OK;
+}
+
 int lpbox_policy_f32_layout(int tokens, long *weight_floats) {
     if (tokens != 20 && tokens != 5) return fail(LPBOX_E_BADARG, "tokens must be 20 (LP) or 5 (segmentation)");
     if (weight_floats) *weight_floats = policy_f32_weight_floats(tokens);

@@ -35,6 +35,10 @@ struct PolicyArgs {
 size_t policy_lds_bytes();
 hipError_t policy_launch_body(const PolicyArgs &pa, int tokens, hipStream_t s);
 
+// the encoder in f32 on v_mfma_f32_16x16x4_f32 (lpbox_policy_f32_kernels.hip); pa.weights = f32 fragments, pa.out = float [rows][TOK*128]
+long policy_f32frag_floats();
+hipError_t policy_launch_body_f32(const PolicyArgs &pa, int tokens, hipStream_t s);
+
 // the whole network in fp32, one workgroup per variable (reference arithmetic; used for decisions near a threshold)
 long policy_f32_weight_floats(int tokens);
 hipError_t policy_launch_f32(const double *x, const long long *row_off, long rows, int tokens, int tok_stride, const float *W,

@@ -46,6 +46,8 @@ SYMBOLS = {
     "lpbox_seg_get_x_history": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "lpbox_policy_layout": (C.c_int, [C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
     "lpbox_policy_encode_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lpbox_policy_f32frag_layout": (C.c_int, [C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
+    "lpbox_policy_encode_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lpbox_policy_f32_layout": (C.c_int, [C.c_int, C.POINTER(C.c_long)]),
     "lpbox_policy_score_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lpbox_policy_rescore_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),

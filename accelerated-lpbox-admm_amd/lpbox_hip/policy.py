@@ -159,6 +159,93 @@ def _pack_fragments(w):
     return v.reshape(NT * KS * 64 * 8).to(torch.float16)
 
 
+def _pack_fragments_f32(w):
+    """(K, N) fp32 matrix -> A-operand fragments of v_mfma_f32_16x16x4_f32 in the order csrc/lpbox_policy_f32_kernels.hip streams them:
+    fragment (n-tile, k-block of 16) at n-tile*KB + kb, float s of lane l = W[16 kb + 4 (l>>4) + s][16 nt + (l&15)] (the lane's four floats are
+    the four k-steps of the block: the activations are read from LDS as one float4 in the same k order)."""
+    K, N = w.shape
+    assert K % 16 == 0 and N % 16 == 0
+    KB, NT = K // 16, N // 16
+    v = w.reshape(KB, 4, 4, NT, 16).permute(3, 0, 1, 4, 2)        # (nt, kb, kq, i, s); lane = 16 kq + i
+    return v.reshape(-1).to(torch.float32)
+
+
+class MfmaFp32Policy:
+    """The reference's float32 arithmetic at usable speed: the encoder as ONE fused kernel on v_mfma_f32_16x16x4_f32 (f32 in, f32
+    accumulate: a k-ordered fmaf chain, no reduced-precision step; C-ABI lpbox_policy_encode_f32) + the MLP head as three fp32 GEMMs.
+    Same interface as FusedEarlyFixPolicy; agreement with the reference module: rounding (tested at 1e-4 on the sigmoid against the
+    reference-generated golden vectors, 2e-5 against EarlyFixPolicy)."""
+
+    def __init__(self, state_dict, tokens=20, device="cuda", chunk_rows=131072):
+        import ctypes as C
+        from . import _lib
+        self._L, self._check = _lib.load(), _lib.check
+        self.chunk_rows = int(chunk_rows)      # bounds the flattened activation buffer (rows x tokens*128 fp32 = 1.3 GB at 20 tokens)
+        ref = EarlyFixPolicy(state_dict, tokens=tokens, device="cpu")
+        self.tokens, self.device = tokens, torch.device(device)
+        wf, cf = C.c_long(), C.c_long()
+        self._check(self._L.lpbox_policy_f32frag_layout(tokens, C.byref(wf), C.byref(cf)), "lpbox_policy_f32frag_layout")
+        frags, consts = [], [ref.w_in.reshape(-1), ref.b_in.reshape(-1)]
+        for L in ref.layers:
+            wq, wk, wv = L["w_qkv"][:, :EMBED], L["w_qkv"][:, EMBED:2 * EMBED], L["w_qkv"][:, 2 * EMBED:]
+            for half in range(2):
+                c = slice(64 * half, 64 * half + 64)                            # heads 4 half .. 4 half + 3
+                frags.append(_pack_fragments_f32(torch.cat([wq[:, c] * 0.25, wk[:, c], wv[:, c]], dim=1)))   # 1/sqrt(16) folded into Q (exact)
+            frags.append(_pack_fragments_f32(L["w_o"]))
+            for c in range(4):
+                frags.append(_pack_fragments_f32(L["w1"][:, 128 * c:128 * c + 128]))
+            for c in range(4):
+                frags.append(_pack_fragments_f32(L["w2"][128 * c:128 * c + 128, :]))
+            consts += [L["n1_s"], L["n1_t"], L["b1"], L["b2"], L["n2_s"], L["n2_t"]]
+        w = torch.cat(frags)
+        c = torch.cat([t.reshape(-1).to(torch.float32) for t in consts])
+        assert w.numel() == wf.value and c.numel() == cf.value, (w.numel(), wf.value, c.numel(), cf.value)
+        self.w, self.c = w.contiguous().to(self.device), c.contiguous().to(self.device)
+        self.head = [(wt.to(self.device, torch.float32), b.to(self.device, torch.float32)) for wt, b in ref.head]
+
+    @classmethod
+    def random(cls, tokens=20, seed=0, **kw):
+        return cls(random_state(tokens, seed), tokens=tokens, **kw)
+
+    @torch.no_grad()
+    def encode(self, flat, row_off, tok_stride):
+        """flat: fp64 CUDA tensor; row_off: int64 CUDA tensor (rows,) of offsets into flat -> fp32 (rows, tokens*128)."""
+        rows = int(row_off.numel())
+        out = torch.empty((rows, self.tokens * EMBED), device=self.device, dtype=torch.float32)
+        if rows:
+            if int(row_off.max().item()) + (self.tokens - 1) * tok_stride + CODE_DIM > flat.numel():
+                raise ValueError("row offsets reach past the end of the iterate buffer")
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            self._check(self._L.lpbox_policy_encode_f32(flat.data_ptr(), row_off.contiguous().data_ptr(), rows, self.tokens, int(tok_stride),
+                                                        self.w.data_ptr(), self.c.data_ptr(), out.data_ptr(), stream),
+                        "lpbox_policy_encode_f32")
+        return out
+
+    @torch.no_grad()
+    def logits_from_xiters(self, flat, row_off, tok_stride=None):
+        out = torch.empty(row_off.numel(), device=self.device, dtype=torch.float32)
+        for r0 in range(0, row_off.numel(), self.chunk_rows):
+            z = self.encode(flat, row_off[r0:r0 + self.chunk_rows], CODE_DIM if tok_stride is None else tok_stride)
+            for k, (w, b) in enumerate(self.head):
+                z = torch.addmm(b, z, w)
+                if k < 3:
+                    z = torch.relu(z)
+            out[r0:r0 + self.chunk_rows] = z.reshape(-1)
+        return out
+
+    @torch.no_grad()
+    def scores_from_xiters(self, flat, row_off, tok_stride=None, logits=False):
+        lg = self.logits_from_xiters(flat, row_off, tok_stride)
+        return (torch.sigmoid(lg), lg) if logits else torch.sigmoid(lg)
+
+    def __call__(self, x):
+        x = x.to(self.device, torch.float64).contiguous()
+        if x.dim() != 3 or x.shape[1] != self.tokens or x.shape[2] != CODE_DIM:
+            raise ValueError("expected (rows, %d, %d), got %s" % (self.tokens, CODE_DIM, tuple(x.shape)))
+        off = torch.arange(x.shape[0], device=self.device, dtype=torch.int64) * (self.tokens * CODE_DIM)
+        return self.scores_from_xiters(x.reshape(-1), off, CODE_DIM)
+
+
 class HipFp32Policy:
     """The whole network (encoder + MLP head) in fp32 by ONE plain HIP kernel, one workgroup per variable (C-ABI
     lpbox_policy_score_f32): the reference's float32 arithmetic on the device without torch in the path.  Slow by design (FMA

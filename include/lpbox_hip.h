@@ -120,6 +120,13 @@ int lpbox_seg_get_x_history(lpbox_t *h, int first, int count, double *out);
 int lpbox_policy_layout(int tokens, long *weight_halves, long *const_floats);
 int lpbox_policy_encode_f16(const double *x_dev, const long long *row_off_dev, long rows, int tokens, int tok_stride,
                             const void *weights_dev, const float *consts_dev, void *out_dev, void *hip_stream);
+/* The same encoder in FLOAT32 on the matrix cores (v_mfma_f32_16x16x4_f32: f32 in, f32 accumulate -- the reference's arithmetic, LP/mha.py
+ * evaluates in float32) at usable speed.  weights_dev: f32 fragments packed by lpbox_hip/policy.py (lpbox_policy_f32frag_layout gives the
+ * count; csrc/lpbox_policy_f32_kernels.hip documents the order), consts_dev: the SAME constant block as lpbox_policy_encode_f16.
+ * out_dev: float [rows][tokens*128].  Asynchronous on hip_stream. */
+int lpbox_policy_f32frag_layout(int tokens, long *weight_floats, long *const_floats);
+int lpbox_policy_encode_f32(const double *x_dev, const long long *row_off_dev, long rows, int tokens, int tok_stride,
+                            const float *weights_dev, const float *consts_dev, float *out_dev, void *hip_stream);
 /* The whole network -- encoder and MLP head -- in fp32 on the device, one workgroup per variable: the reference's arithmetic
  * (LP/mha.py evaluates in float32), for fixing decisions near a threshold and as the fp32 check of the fused kernel; not a fast
  * path.  weights_dev: floats in the order csrc/lpbox_policy_kernels.hip documents (lpbox_policy_f32_layout gives the count);

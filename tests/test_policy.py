@@ -108,6 +108,36 @@ def test_fp32_hip_kernel_matches_reference(tag, tokens):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("tag,tokens", [("lp", 20), ("seg", 5)])
+def test_fp32_mfma_encoder_matches_reference(tag, tokens):
+    """lpbox_policy_encode_f32 (the fused encoder on v_mfma_f32_16x16x4_f32, the reference's float32 arithmetic at usable speed) + fp32 head:
+    1e-4 on the sigmoid against the golden vectors the reference module produced, 2e-5 against the fp32 torch evaluation and against the
+    plain fp32 HIP kernel, ragged row counts (a last workgroup with fewer variables), strided / overlapping tokens."""
+    sd = deterministic_state(P.reference_state_shapes(tokens))
+    m32, ref = P.MfmaFp32Policy(sd, tokens=tokens, device="cuda"), P.EarlyFixPolicy(sd, tokens=tokens, device="cuda")
+    x = torch.from_numpy(FIX[tag + "_x"]).cuda()
+    got = m32(x).cpu().numpy()
+    assert np.abs(got - FIX[tag + "_sigmoid"]).max() < 1e-4
+    assert np.abs(got - ref(x).cpu().numpy()).max() < 2e-5
+    _, logit = m32.scores_from_xiters(x.to(torch.float64).reshape(-1), torch.arange(x.shape[0], device="cuda") * (tokens * 5), 5, logits=True)
+    assert np.abs(logit.cpu().numpy() - FIX[tag + "_logit"]).max() < 5e-4 * max(1.0, np.abs(FIX[tag + "_logit"]).max())
+    # reference-style initial weights, a row count that is not a multiple of the workgroup's variables, rows in permuted order
+    sd2 = P.random_state(tokens, seed=5)
+    m2, r2, h2 = P.MfmaFp32Policy(sd2, tokens=tokens), P.EarlyFixPolicy(sd2, tokens=tokens, device="cuda"), P.HipFp32Policy(sd2, tokens=tokens)
+    g = torch.Generator().manual_seed(3)
+    xr = torch.rand(1003, tokens, 5, generator=g).cuda()
+    perm = torch.randperm(1003, generator=g).cuda()
+    a = m2.scores_from_xiters(xr.to(torch.float64).reshape(-1), perm * (tokens * 5), 5)
+    assert (a - r2(xr)[perm]).abs().max().item() < 2e-5
+    assert (a - h2(xr)[perm]).abs().max().item() < 2e-5
+    if tokens == 5:      # SEG-style overlapping tokens: token j = iterates j .. j+4 of a 10-iterate window (stride 1)
+        w = torch.rand(300, 10, generator=g, dtype=torch.float64).cuda()
+        xs = torch.stack([w[:, j:j + 5] for j in range(5)], dim=1).to(torch.float32)
+        b = m2.scores_from_xiters(w.reshape(-1), torch.arange(300, device="cuda") * 10, 1)
+        assert (b - r2(xs)).abs().max().item() < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,tokens", [("lp", 20), ("seg", 5)])
 def test_fused_policy_takes_the_fp32_fix_decisions(tag, tokens):
     """deter_fix_2 thresholds the score at 0.9 / 0.1: with the default decision band the fused path re-scores the rows near a
     threshold in fp32, so its FIX VECTOR equals the one the fp32 network (= the reference's arithmetic, pinned by the golden

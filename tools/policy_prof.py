@@ -5,12 +5,13 @@ import torch
 from lpbox_hip.policy import EarlyFixPolicy
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 128000
 mode = sys.argv[2] if len(sys.argv) > 2 else "fp32"
-dt = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16, "fused": None, "hip32": None}[mode]
+dt = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16, "fused": None, "hip32": None, "mfma32": None}[mode]
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
-from lpbox_hip.policy import FusedEarlyFixPolicy, HipFp32Policy
-pol = FusedEarlyFixPolicy.random(tokens=20, seed=0) if mode == "fused" else HipFp32Policy.random(tokens=20, seed=0) if mode == "hip32" else EarlyFixPolicy.random(tokens=20, seed=0, device="cuda", dtype=dt)
+from lpbox_hip.policy import FusedEarlyFixPolicy, HipFp32Policy, MfmaFp32Policy
+pol = (FusedEarlyFixPolicy.random(tokens=20, seed=0) if mode == "fused" else HipFp32Policy.random(tokens=20, seed=0) if mode == "hip32"
+       else MfmaFp32Policy.random(tokens=20, seed=0) if mode == "mfma32" else EarlyFixPolicy.random(tokens=20, seed=0, device="cuda", dtype=dt))
 x = torch.rand(rows, 20, 5, device="cuda")
-if mode in ("fused", "hip32"):
+if mode in ("fused", "hip32", "mfma32"):
     xf = x.to(torch.float64).reshape(-1); off = torch.arange(rows, device="cuda") * 100
     _call = pol.__call__; pol_call = lambda _x: pol.scores_from_xiters(xf, off)
 else:
