@@ -11,6 +11,7 @@ timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv 
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/prof_write -o write -- python3 $R/bench.py --config 2 --steps 2 --warmup 1 --cpu-sample 0 > $O/prof_write.log 2>&1 &&
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c4 -o c4 -- python3 $R/bench.py --config 4 --steps 2 --warmup 1 --cpu-sample 0 > $O/prof_c4.log 2>&1 &&
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_policy -o policy -- python3 $R/tools/policy_prof.py 128000 fused 10 > $O/prof_policy.log 2>&1 &&
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_policy32 -o policy32 -- python3 $R/tools/policy_prof.py 128000 mfma32 5 > $O/prof_policy32.log 2>&1 &&
 LPBOX_BIG_NOGRAPH=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_big -o big -- python3 $R/bench.py --config 5 --steps 2 --warmup 1 --cpu-sample 0 > $O/prof_big.log 2>&1 &&
 LPBOX_SEG_NOGRAPH=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_seg -o seg -- python3 $R/bench.py --config 3 --steps 3 --warmup 1 --cpu-sample 0 > $O/prof_seg.log 2>&1
 echo "collect_profiles rc=$?"

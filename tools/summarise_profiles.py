@@ -29,6 +29,8 @@ if os.path.exists(os.path.join(O, "prof_segb", "segb_kernel_stats.csv")):
 if os.path.exists(os.path.join(O, "prof_c4", "c4_kernel_stats.csv")):
     stats(os.path.join(O, "prof_c4", "c4_kernel_stats.csv"), os.path.join(P, rnd + "_config4_kernel_stats.csv"))
 stats(os.path.join(O, "prof_policy", "policy_kernel_stats.csv"), os.path.join(P, rnd + "_policy_kernel_stats.csv"))
+if os.path.exists(os.path.join(O, "prof_policy32", "policy32_kernel_stats.csv")):
+    stats(os.path.join(O, "prof_policy32", "policy32_kernel_stats.csv"), os.path.join(P, rnd + "_policy_f32_kernel_stats.csv"))
 stats(os.path.join(O, "prof_big", "big_kernel_stats.csv"), os.path.join(P, rnd + "_big_kernel_stats.csv"))
 stats(os.path.join(O, "prof_seg", "seg_kernel_stats.csv"), os.path.join(P, rnd + "_seg_kernel_stats.csv"))
 fetch_kb, nf = counter(os.path.join(O, "prof_fetch", "fetch_counter_collection.csv"), "FETCH_SIZE", "lp_window_kernel")
