@@ -31,8 +31,15 @@ int main(int argc, char **argv) {
     const int lds_kb = argc > 1 ? atoi(argv[1]) : 78, threads = argc > 2 ? atoi(argv[2]) : 256, groups = argc > 3 ? atoi(argv[3]) : 8192;
     unsigned *bad; (void)hipMalloc(&bad, 8); (void)hipMemset(bad, 0, 8);
     (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_kb * 1024);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL(k, dim3(groups), dim3(threads), lds_kb * 1024, 0, bad, lds_kb * 256, 6);      // warm
+    (void)hipEventRecord(e0, 0);
     hipLaunchKernelGGL(k, dim3(groups), dim3(threads), lds_kb * 1024, 0, bad, lds_kb * 256, 6);
+    (void)hipEventRecord(e1, 0);
     unsigned h[2]; (void)hipMemcpy(h, bad, 8, hipMemcpyDeviceToHost);
-    printf("lds %d KB, %d threads, %d groups: %u wrong words (%s)\n", lds_kb, threads, groups, h[0], hipGetErrorString(hipGetLastError()));
+    float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+    // (two workgroups per CU show as about half the time per KB of the one-per-CU sizes)
+    printf("lds %d KB, %d threads, %d groups: %u wrong words, %.2f ms = %.3f us per workgroup-KB (%s)\n", lds_kb, threads, groups, h[0], ms,
+           1e3 * ms / groups / lds_kb, hipGetErrorString(hipGetLastError()));
     return h[0] != 0;
 }

@@ -4,17 +4,20 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#ifndef NA
+#define NA 600          // large enough that the array cannot be promoted to registers: real scratch (check .private_segment_fixed_size)
+#endif
 __global__ void k(unsigned *bad, int spin, int salt) {
     extern __shared__ unsigned lds[];
-    unsigned a[24];
+    unsigned a[NA];
     const unsigned id = blockIdx.x * blockDim.x + threadIdx.x;
-    for (int i = 0; i < 24; i++) a[(i * 7 + salt) % 24] = id * 31u + i;
+    for (int i = 0; i < NA; i++) a[(i * 7 + salt) % NA] = id * 31u + i;
     lds[threadIdx.x] = id;
     __syncthreads();
     unsigned acc = 0;
-    for (int s = 0; s < spin; s++) { acc += lds[(threadIdx.x + s) % blockDim.x]; a[(s + salt) % 24] += 0u; __builtin_amdgcn_s_sleep(1); }
+    for (int s = 0; s < spin; s++) { acc += lds[(threadIdx.x + s) % blockDim.x]; a[(s + salt) % NA] += 0u; __builtin_amdgcn_s_sleep(1); }
     unsigned wrong = 0;
-    for (int i = 0; i < 24; i++) wrong += a[(i * 7 + salt) % 24] != id * 31u + i;
+    for (int i = 0; i < NA; i++) wrong += a[(i * 7 + salt) % NA] != id * 31u + i;
     if (wrong) atomicAdd(bad, wrong);
     if (acc == 0xFFFFFFFFu) bad[1] = acc;
 }
