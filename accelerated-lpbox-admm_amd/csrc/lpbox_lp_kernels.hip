@@ -140,6 +140,17 @@ __device__ __forceinline__ void build_list(Lists<C> &g, int begin, int end, cons
     g.wlen[S] = wave_max_int(len < CAP ? len : CAP);
 }
 
+// Make every register address of a list live at one point.  In the register-lean variants the allocator parks a few list addresses in
+// scratch during the outer phases and, left alone, fetches them back one at a time right in front of their LDS gather -- a scratch round
+// trip per entry inside a dependent chain.  Touching them together turns that into one batch of loads ahead of the gather.
+template <typename C>
+__device__ __forceinline__ void touch_list(const Lists<C> &g) {
+#ifndef LPBOX_NO_TOUCH
+#pragma unroll
+    for (int k = 0; k < C::total; k++) { const unsigned v = g.addr[k]; asm volatile("" : : "v"(v)); }
+#endif
+}
+
 constexpr int GCH = 4;   // gathers of one slot issued together before their (ordered) additions
 
 template <typename C>
@@ -569,6 +580,7 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
     constexpr int GX2 = T * EPT + 2;             // the second n-vector of gx, as an immediate ds_read offset in doubles
     auto rows_gather_at = [&](auto COMPC, double (&out)[EPT]) {
         double part[EPT];
+        if constexpr (LEAN) touch_list(rl);
         gather_all<RCAPS, 8, decltype(COMPC)::value>(rl, s_rs_col, op_add, part);
         static_for<EPT>([&](auto S) {
             constexpr int s = decltype(S)::value;
@@ -590,6 +602,7 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
     auto cols_gather = [&](auto COMPC, auto op, double (&out)[EPT]) {
         constexpr int COMP = decltype(COMPC)::value;
         double own[EPT];
+        if constexpr (LEAN) { touch_list(cl); touch_list(hl); }
         gather_all<CCAPS, 24, COMP>(cl, s_cs_row, op, own);
         if constexpr (HCAPS::total > 0) {
             double hp[EPT];
@@ -606,6 +619,7 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
     };
     auto cols_gather2 = [&](auto opa, auto opb, double (&outA)[EPT], double (&outB)[EPT]) {      // components 0 and 1 (rhs assembly)
         double ownA[EPT], ownB[EPT];
+        if constexpr (LEAN) { touch_list(cl); touch_list(hl); }
         gather_all2<CCAPS, 24, 0, 1>(cl, s_cs_row, opa, opb, ownA, ownB);
         if constexpr (HCAPS::total > 0) {
             double hA[EPT], hB[EPT];
