@@ -417,11 +417,20 @@ template <bool MEM, int N, int STRIDE>
 struct RowVec {
     double r[MEM ? 1 : N];
     double *lds;
+    // (MEM: the element's address is formed at the access.  Left to itself the compiler hoists the loop-invariant addresses of all slots
+    //  out of the iteration loop, runs out of registers, parks them in scratch and fetches each one back right in front of its LDS access:
+    //  a scratch round trip inside every dependent y3 / z4 chain of the outer phases -- an and + shift is cheaper.)
+    static __device__ __forceinline__ int at(int idx) {
+#ifndef LPBOX_NO_OPAQUE_ROWVEC
+        asm volatile("" : "+v"(idx));
+#endif
+        return idx * STRIDE;
+    }
     __device__ __forceinline__ double get(int s, int idx, bool leader) const {
-        if constexpr (MEM) return leader ? lds[idx * STRIDE] : 0.0; else return r[s];
+        if constexpr (MEM) return leader ? lds[at(idx)] : 0.0; else return r[s];
     }
     __device__ __forceinline__ void set(int s, int idx, bool leader, double v) {
-        if constexpr (MEM) { if (leader) lds[idx * STRIDE] = v; } else r[s] = v;
+        if constexpr (MEM) { if (leader) lds[at(idx)] = v; } else r[s] = v;
     }
 };
 
