@@ -725,11 +725,24 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
                     if constexpr (!LEAN) { y1c[s] = y1n; uc[s] = u; }
                 }
                 // y3 = max(0, f - E x - z4/rho4), LPcpp:824-828
+                if constexpr (LEAN) {
+                    // LDS-backed row vectors: the leader lane's whole read-compute-write in ONE predicated region with one index (four
+                    // separate predicated accesses were four branches, each fetching the spilled index back from scratch first)
+                    if (rvalid(s)) {
+                        const int i = RowVec<true, EPT, 1>::at(rgl(s));
+                        const double fs = f.lds[i], z4s = z4.lds[3 * i];
+                        const double v = fs - Ex[s] - z4s / r4;
+                        const double y3s = v < 0 ? 0 : v;
+                        y3.lds[i] = y3s;
+                        gl[3 * i] = fs - y3s;
+                    }
+                } else {
                 const double fs = f.get(s, rgl(s), rvalid(s)), z4s = z4.get(s, rgl(s), rvalid(s));
                 const double v = fs - Ex[s] - z4s / r4;
                 const double y3s = v < 0 ? 0 : v;
                 y3.set(s, rgl(s), rvalid(s), y3s);
-                if (rvalid(s)) { gl[3 * rgl(s)] = fs - y3s; if constexpr (!LEAN) gl[3 * rgl(s) + 1] = z4s; }
+                if (rvalid(s)) { gl[3 * rgl(s)] = fs - y3s; gl[3 * rgl(s) + 1] = z4s; }
+                }
             }
             return part;
         };
@@ -1060,8 +1073,17 @@ __global__ void __launch_bounds__(T) lp_window_kernel(LpBatchDev bd, int iter_st
             rows_gather(Ex);                                          // E*x: feeds z4 now and y3 of the next iteration
 #pragma unroll
             for (int s = 0; s < EPT; s++) {
+                if constexpr (LEAN) {
+                    if (rvalid(s)) {                                  // (one predicated region per slot: see prepare())
+                        const int i = RowVec<true, EPT, 1>::at(rgl(s));
+                        const double d = g4 * ((Ex[s] + y3.lds[i]) - f.lds[i]);
+                        const double z4o = z4.lds[3 * i];
+                        z4.lds[3 * i] = (!l2f && it == iter_start) ? d : z4o + d;
+                    }
+                } else {
                 const double d = g4 * ((Ex[s] + y3.get(s, rgl(s), rvalid(s))) - f.get(s, rgl(s), rvalid(s)));
                 z4.set(s, rgl(s), rvalid(s), (!l2f && it == iter_start) ? d : z4.get(s, rgl(s), rvalid(s)) + d);   // :920-923 (plain loop overwrites on its first iteration)
+                }
             }
             // ---------------- residual norms, objective (:931-1011); the next iteration's first half rides along ----------------
             double lg[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};            // LOG: |y1|^2 |y2|^2 |y3|^2 |z1|^2 |z2|^2 |z4|^2 of THIS iteration (before prepare() moves y3 on)
