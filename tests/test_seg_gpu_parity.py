@@ -95,12 +95,14 @@ def test_full_resolution_image_windows_bit_exact():
     compare_state(g, o, "full-res")
 
 
-def test_full_resolution_legacy_solve_bit_exact_to_convergence():
-    """BASELINE config 3 as bench.py runs it: ADMM_bqp_unconstrained_legacy (SEGcpp:1200-1380) on the full 187 500-variable problem, all
-    the way to its stop test -- energy, stop reason, outer and PCG iteration counts, final iterate and duals, binary solution."""
+@pytest.mark.parametrize("image", ["0.jpg", "7.jpg"])
+def test_full_resolution_legacy_solve_bit_exact_to_convergence(image):
+    """BASELINE config 3 as bench.py runs it: ADMM_bqp_unconstrained_legacy (SEGcpp:1200-1380) on the full-resolution problem of both sample
+    images (187 500 variables for 0.jpg), all the way to its stop test -- energy, stop reason, outer and PCG iteration counts, final iterate
+    and duals, binary solution."""
     from lpbox_hip.seg import load_gray
-    n = load_gray(os.path.join(GOLDEN, "seg", "0.jpg")).size
-    g, o = make_pair(n)
+    n = load_gray(os.path.join(GOLDEN, "seg", image)).size
+    g, o = make_pair(n, image)
     eg, eo = g.solve_iter(), o.solve_iter()
     assert eg == eo
     assert g.stop() == (o.last_stop, o.legacy_iter_plus1)
