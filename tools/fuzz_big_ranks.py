@@ -1,7 +1,7 @@
 """Differential fuzz of the VARIABLE-SHARDED large-instance path: W = 2, 3 ranks on the one GPU (contributions exchanged over gloo through
 the callback transport), odd-structured instances from tools/fuzz_big.py -- few variables per rank, row blocks of a handful of rows, empty
 rows, very long rows -- reference arithmetic and the opt-in comm-lean PCG, against the oracle's rank model bit for bit.
-usage: python tools/fuzz_big_ranks.py [cases=6] [seed=0] [first_case=0]"""
+usage: python tools/fuzz_big_ranks.py [cases=6] [seed=0] [first_case=0] [iterations=10]   (iterations = 20000: to convergence)"""
 import os, socket, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'accelerated-lpbox-admm_amd'), os.path.join(ROOT, 'tests'), os.path.join(ROOT, 'tools')]
@@ -58,10 +58,11 @@ def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 6
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     first = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    iters = int(sys.argv[4]) if len(sys.argv) > 4 else 10
     bad = 0
     for c in range(first, first + cases):
         for world, mode in ((2, "reference"), (3, "lean")) if c % 2 == 0 else ((3, "reference"), (2, "lean")):
-            ok, I, kind = run_case(seed, c, world, mode)
+            ok, I, kind = run_case(seed, c, world, mode, iters)
             print("case %2d kind %d n %5d l %5d nnz %7d W %d %-9s: %s" % (c, kind, I["n"], I["l"], len(I["rowidx"]), world, mode, "ok" if ok else "MISMATCH"), flush=True)
             bad += not ok
     print("fuzz_big_ranks: %d runs differ" % bad)
