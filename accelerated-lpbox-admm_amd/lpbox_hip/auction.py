@@ -142,8 +142,11 @@ def stream_instances(n_items, n_bids, first, count, fixture=None, workers=1, che
         i += take
     if workers > 1 and len(jobs) > 1:
         import multiprocessing as mp
-        with mp.get_context("spawn").Pool(min(workers, len(jobs))) as pool:
-            parts = pool.map(_block, jobs)
+        from concurrent.futures import ProcessPoolExecutor
+        # an executor, not mp.Pool: a worker that cannot start (e.g. a __main__ without a file under spawn) raises BrokenProcessPool
+        # here; mp.Pool would respawn it for ever
+        with ProcessPoolExecutor(min(workers, len(jobs)), mp_context=mp.get_context("spawn")) as pool:
+            parts = list(pool.map(_block, jobs))
     else:
         parts = [_block(j) for j in jobs]
     out = [inst for p in parts for inst in p]
