@@ -220,9 +220,12 @@ int finalize(lpbox_t *h) {
         const int wv = (slot & 1) ? (W - 1 - r) : r;
         return slot * h->T + wv * 64;
     };
-    // bank-aware lane choice (round 1): worth < 2 % per iteration once long columns are split, and O(n * 32 * row length) host work;
-    // off by default, LPBOX_LP_BANKAWARE=1 turns it on (tools/lottery.sh measures both)
-    const bool noconflict = getenv("LPBOX_LP_BANKAWARE") == nullptr || getenv("LPBOX_LP_NOCONFLICT") != nullptr;
+    // bank-aware lane choice (round 1): O(n * 32 * row length) host work.  One slot per thread: worth < 3 % per iteration once the long
+    // columns are split, and the direct x-update wants the plain row placement: off.  Four slots per thread (n > 1024): 4-5 % per
+    // iteration, measured over all eight rank shards of the j=500/k=2000 stream: on.  LPBOX_LP_BANKAWARE=1 / =0 overrides either way
+    // (tools/lottery.sh measures both).
+    const char *ba = getenv("LPBOX_LP_BANKAWARE");
+    const bool noconflict = getenv("LPBOX_LP_NOCONFLICT") != nullptr || !(ba ? atoi(ba) != 0 : h->EPT >= 4);
     for (size_t i = 0; i < B; i++) {
         LpInstance &I = h->inst[i];
         // ---- rows: G lanes share a row so that no lane walks more than ~L entries; lane g takes entries g, g+G, ... ----
