@@ -81,6 +81,36 @@ def test_tuning_geometries_bit_exact(monkeypatch, threads, fixture, geometry):
     assert g.batch.counters() == (o.total_outer_iters, o.total_pcg_iters)
 
 
+@pytest.mark.parametrize("fixture,setting", [("lp_500_2000_seed0.npz", None), ("lp_500_2000_seed0.npz", "0"), ("lp_100_500_seed0.npz", "1")])
+def test_both_lane_choices_bit_exact(monkeypatch, fixture, setting):
+    """The lane (= LDS bank class) of a variable and the storage index of a row are free parameters of the layout: the four-slot variant
+    takes the bank-aware choice by default, the one-slot variants the plain one, LPBOX_LP_BANKAWARE=0/1 overrides.  Each is its own
+    summation order, mirrored by the oracle through the exported layout: an early-fixing window and a plain window, every iterate.
+    The two choices really are different layouts (the positions of the variables differ)."""
+    I = lp_instances(fixture)[1]
+    if setting is None:
+        monkeypatch.delenv("LPBOX_LP_BANKAWARE", raising=False)
+    else:
+        monkeypatch.setenv("LPBOX_LP_BANKAWARE", setting)
+    g = gpu_solver(I)
+    pos = g.batch.layout(0)                      # (the layout is built, with the setting read, at the first call that needs it)
+    monkeypatch.setenv("LPBOX_LP_BANKAWARE", "1" if setting == "0" else "0")
+    other = gpu_solver(I).batch.layout(0)
+    monkeypatch.delenv("LPBOX_LP_BANKAWARE")
+    assert not np.array_equal(pos, other)
+    o = oracle_like(g, I)
+    vec, num = np.zeros(I["n"]), 0
+    for w in range(2):
+        assert g.solve_iter_l2f(w * 100, (w + 1) * 100, vec, num) == o.solve_iter_l2f(w * 100, (w + 1) * 100, vec, num)
+        xg, xo = g.get_x_iters_2d(100), o.get_x_iters_2d(100)
+        assert bits_equal(xg, xo), f"window {w}"
+        compare_state(g, o, f"window {w}")
+        vec, num = scripted_fix_vec(xg, lo=0.05, hi=0.95, last=30)
+    assert g.solve_iter(200, 500) == o.solve_iter(200, 500)
+    compare_state(g, o, "plain window")
+    assert g.batch.counters() == (o.total_outer_iters, o.total_pcg_iters)
+
+
 @pytest.mark.parametrize("idx", [0, 1, 2])
 def test_full_plain_solve_bit_exact(idx):
     I = lp_instances("lp_100_500_seed0.npz")[idx]
