@@ -463,15 +463,20 @@ int finalize(lpbox_t *h) {
                 }
                 return (size_t)0;
             };
+            std::vector<size_t> ins(I.rowptr[I.l]);                 // gather instruction of every entry, row-major
+            for (int r = 0; r < I.l; r++)
+                for (int e = I.rowptr[r]; e < I.rowptr[r + 1]; e++) ins[e] = instr_of(I.colidx[e], r) * 32;
+            // (re-choosing every row's class against all the others in further passes was measured: 77.9 / 78.1 / 78.2 us per iteration
+            // of the four-slot variant with 0 / 3 / 10 passes -- nothing; one greedy pass stays)
             for (int r : order) {
                 int best = -1; long best_cost = 0;
                 for (int c = 0; c < 32; c++) {
                     if (usedc[c] >= cap) continue;
                     long cost = 0;
-                    for (int e = I.rowptr[r]; e < I.rowptr[r + 1]; e++) cost += cnt[instr_of(I.colidx[e], r) * 32 + c];
+                    for (int e = I.rowptr[r]; e < I.rowptr[r + 1]; e++) cost += cnt[ins[e] + c];
                     if (best < 0 || cost < best_cost) { best = c; best_cost = cost; }
                 }
-                for (int e = I.rowptr[r]; e < I.rowptr[r + 1]; e++) cnt[instr_of(I.colidx[e], r) * 32 + best]++;
+                for (int e = I.rowptr[r]; e < I.rowptr[r + 1]; e++) cnt[ins[e] + best]++;
                 rpos[r] = best + 32 * usedc[best]++;
             }
         }
